@@ -1,0 +1,108 @@
+/*
+ * ir2rgb_hip.h -- C ABI of libir2rgb_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary for the ir2rgb hot path: what the reference binds through
+ * three pybind11 extension modules (correlation_cuda / resample2d_cuda / channelnorm_cuda)
+ * and what its models/networks.py obtains from cuDNN, expressed as plain C entry points
+ * that take raw device pointers, explicit sizes and a HIP stream.  No torch types cross it.
+ *
+ * Conventions
+ *   - every pointer is a device pointer unless the name ends in `_host`;
+ *   - tensors are dense, in the layout named in the comment of each function;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is
+ *     enqueued asynchronously on it, nothing synchronises the host;
+ *   - return value: 0 on success, a positive hipError_t if a launch failed, or a negative
+ *     IR2RGB_E* code for argument errors detected on the host.  Nothing throws.
+ *   - "reference" paths are relative to /root/reference.
+ */
+#ifndef IR2RGB_HIP_H
+#define IR2RGB_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IR2RGB_OK 0
+#define IR2RGB_EINVAL (-1)  /* bad size / parameter combination            */
+#define IR2RGB_ENOSUP (-2)  /* valid in the reference, not implemented here */
+#define IR2RGB_EALIGN (-3)  /* pointer or pitch not aligned as required     */
+
+/* element types of activation / weight buffers */
+#define IR2RGB_F32 0
+#define IR2RGB_BF16 1
+#define IR2RGB_F16 2
+
+/* library / build identification: "ir2rgb_hip <version> gfx950" */
+const char *ir2rgb_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * FlowNet2 operators (fp32, NCHW)
+ * ------------------------------------------------------------------------------------------ */
+
+/* Output geometry of the cost volume.
+ * Replaces the sizing arithmetic in
+ *   models/flownet2_pytorch/networks/correlation_package/correlation_cuda.cc:25-42. */
+int ir2rgb_correlation_out_shape(int C, int H, int W, int pad_size, int kernel_size, int max_displacement,
+                                 int stride1, int stride2, int *outC, int *outH, int *outW);
+
+/* Cost volume forward.  in1,in2 [N,C,H,W] -> out [N,outC,outH,outW]; out is fully written
+ * (no pre-zeroing needed).  Unlike the reference no padded channels-last scratch copies
+ * (rInput1/rInput2) are needed.
+ * Replaces correlation_cuda.forward:
+ *   correlation_package/correlation_cuda.cc:10-87 and
+ *   correlation_package/correlation_cuda_kernel.cu:46-147, :336-427. */
+int ir2rgb_correlation_fwd(const float *in1, const float *in2, float *out, int N, int C, int H, int W,
+                           int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
+                           void *stream);
+
+/* Cost volume backward.  gout [N,outC,outH,outW] -> gin1, gin2 [N,C,H,W] (fully written).
+ * stride1 must be 1 (the reference's launch geometry writes out of bounds otherwise).
+ * Replaces correlation_cuda.backward:
+ *   correlation_package/correlation_cuda.cc:89-167 and
+ *   correlation_package/correlation_cuda_kernel.cu:150-334, :430-564. */
+int ir2rgb_correlation_bwd(const float *in1, const float *in2, const float *gout, float *gin1, float *gin2,
+                           int N, int C, int H, int W, int pad_size, int kernel_size, int max_displacement,
+                           int stride1, int stride2, void *stream);
+
+/* Flow warp forward.  img [N,C,H,W], flow [N,2,H,W] (pixels; channel 0 = dx, 1 = dy)
+ * -> out [N,C,H,W].  kernel_size must be 1 (the only value the reference passes; larger
+ * values make its kernel read out of bounds).
+ * Replaces resample2d_cuda.forward:
+ *   resample2d_package/resample2d_cuda.cc:6-13, resample2d_kernel.cu:15-64, :192-232. */
+int ir2rgb_resample2d_fwd(const float *img, const float *flow, float *out, int N, int C, int H, int W,
+                          int kernel_size, void *stream);
+
+/* Flow warp backward.  gout [N,C,H,W] -> gimg [N,C,H,W] (zeroed here, then scattered with
+ * float atomics), gflow [N,2,H,W].  Keeps the reference's truncation-vs-floor quirk.
+ * Replaces resample2d_cuda.backward:
+ *   resample2d_package/resample2d_cuda.cc:15-24, resample2d_kernel.cu:67-190, :234-310. */
+int ir2rgb_resample2d_bwd(const float *img, const float *flow, const float *gout, float *gimg, float *gflow,
+                          int N, int C, int H, int W, int kernel_size, void *stream);
+
+/* Channel L2 norm forward.  in [N,C,H,W] -> out [N,1,H,W].  norm_deg is accepted and
+ * ignored exactly as in the reference.
+ * Replaces channelnorm_cuda.forward:
+ *   channelnorm_package/channelnorm_cuda.cc:6-13, channelnorm_kernel.cu:18-60, :98-129. */
+int ir2rgb_channelnorm_fwd(const float *in, float *out, int N, int C, int H, int W, int norm_deg, void *stream);
+
+/* Channel L2 norm backward.  gin = gout * in / (out + 1e-9).
+ * Replaces channelnorm_cuda.backward:
+ *   channelnorm_package/channelnorm_cuda.cc:16-25, channelnorm_kernel.cu:63-96, :131-177. */
+int ir2rgb_channelnorm_bwd(const float *in, const float *out, const float *gout, float *gin, int N, int C,
+                           int H, int W, int norm_deg, void *stream);
+
+/* Fused FlowNet2 step: warped = resample2d(img2, flow); diff = img1 - warped;
+ * norm = channelnorm(diff).  Any of warped / diff / norm may be NULL to skip that output.
+ * Fuses the three-launch sequence at models/flownet2_pytorch/models.py:109-111 (and
+ * :121-123, :133-137, :146-150) and the confidence test of models/flownet.py:50,56-57
+ * (conf = norm^2 < 0.02 is left to the caller). */
+int ir2rgb_warp_diff_norm_fwd(const float *img1, const float *img2, const float *flow, float *warped,
+                              float *diff, float *norm, int N, int C, int H, int W, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IR2RGB_HIP_H */

@@ -1,0 +1,94 @@
+"""ctypes binding of libir2rgb_hip.so -- the only way the Python side reaches the kernels.
+
+The library is loaded lazily on first use and the load FAILS LOUDLY when the shared object is
+missing (no CPU or eager fallback exists in this package by design).  Prototypes mirror
+include/ir2rgb_hip.h one to one; tests/test_abi.py checks that every symbol the header declares
+is exported and bound here.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libir2rgb_hip.so")
+
+c_int, c_long, c_float, c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
+_pint = ctypes.POINTER(ctypes.c_int)
+P = c_void_p  # device pointer
+
+# name -> (restype, argtypes)
+PROTOTYPES = {
+    "ir2rgb_version": (ctypes.c_char_p, []),
+    "ir2rgb_correlation_out_shape": (c_int, [c_int] * 8 + [_pint] * 3),
+    "ir2rgb_correlation_fwd": (c_int, [P, P, P] + [c_int] * 9 + [P]),
+    "ir2rgb_correlation_bwd": (c_int, [P, P, P, P, P] + [c_int] * 9 + [P]),
+    "ir2rgb_resample2d_fwd": (c_int, [P, P, P] + [c_int] * 5 + [P]),
+    "ir2rgb_resample2d_bwd": (c_int, [P, P, P, P, P] + [c_int] * 5 + [P]),
+    "ir2rgb_channelnorm_fwd": (c_int, [P, P] + [c_int] * 5 + [P]),
+    "ir2rgb_channelnorm_bwd": (c_int, [P, P, P, P] + [c_int] * 5 + [P]),
+    "ir2rgb_warp_diff_norm_fwd": (c_int, [P] * 6 + [c_int] * 4 + [P]),
+}
+
+_lib = None
+
+
+class Ir2rgbError(RuntimeError):
+    """A libir2rgb_hip.so entry point returned non-zero (mirrors the reference's AT_ERROR
+    "CUDA call failed", correlation_cuda.cc:80-84)."""
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `python -m ir2rgb_amd.build` or __graft_entry__.build()). "
+                "ir2rgb_amd has no CPU/eager fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+_ERRNAMES = {-1: "IR2RGB_EINVAL (bad size/parameter)", -2: "IR2RGB_ENOSUP (not supported)",
+             -3: "IR2RGB_EALIGN (misaligned buffer)"}
+
+
+def check(rc, what):
+    if rc != 0:
+        if rc < 0:
+            if rc == -2:
+                raise NotImplementedError(f"{what}: {_ERRNAMES[rc]}")
+            raise ValueError(f"{what}: {_ERRNAMES.get(rc, rc)}")
+        raise Ir2rgbError(f"{what}: HIP call failed (hipError_t {rc})")
+
+
+def current_stream(tensor):
+    import torch
+    return c_void_p(torch.cuda.current_stream(tensor.device).cuda_stream)
+
+
+def require_device(*tensors, dtype=None):
+    """Turn the reference's silent assumptions (CUDA device, dtype, contiguity) into errors."""
+    import torch
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not isinstance(t, torch.Tensor):
+            raise TypeError(f"expected a tensor, got {type(t)}")
+        if not t.is_cuda:
+            raise ValueError("ir2rgb_amd operators run on an AMD GPU only: got a CPU tensor "
+                             "(there is no CPU fallback; use oracle/ for CPU checks)")
+        if dtype is not None and t.dtype != dtype:
+            raise TypeError(f"expected dtype {dtype}, got {t.dtype}")
+        if not t.is_contiguous():
+            raise ValueError("expected a contiguous tensor")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise ValueError(f"tensors on different devices: {dev} vs {t.device}")
+    return dev
