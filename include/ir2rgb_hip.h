@@ -102,6 +102,39 @@ int ir2rgb_channelnorm_bwd(const float *in, const float *out, const float *gout,
 int ir2rgb_warp_diff_norm_fwd(const float *img1, const float *img2, const float *flow, float *warped,
                               float *diff, float *norm, int N, int C, int H, int W, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Generator / discriminator convolutions (half precision NHWC, fp32 accumulate, MFMA)
+ *
+ * These replace what reference models/networks.py gets from torch.nn.Conv2d /
+ * ConvTranspose2d (+ ReflectionPad2d) -> cuDNN for the dense layers of
+ * CompositeGeneratorModule (:141-171), CompositeLocalGeneratorModule (:253-271),
+ * ResnetBlock (:556-580) and NLayerDiscriminator (:678-699).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ir2rgb_conv_desc {
+    int N, Hin, Win, Cin;   /* input  [N,Hin,Win,Cin]  NHWC, Cin % 64 == 0 */
+    int Hout, Wout, Cout;   /* output [N,Hout,Wout,Cout] NHWC              */
+    int kh, kw, stride, pad;
+    int pad_mode;           /* 0: zero padding, 1: reflection padding (nn.ReflectionPad2d) */
+    int transposed;         /* 0: Conv2d, 1: ConvTranspose2d (stride 2; Hout/Wout carry output_padding) */
+    int dtype;              /* IR2RGB_BF16 or IR2RGB_F16: activations and packed weights */
+    int act;                /* fused after bias: 0 none, 1 LeakyReLU(0.2) */
+} ir2rgb_conv_desc;
+
+/* Number of half elements of the packed weight buffer for this convolution (< 0: error). */
+long ir2rgb_conv2d_packed_weight_elems(const ir2rgb_conv_desc *d);
+
+/* Rows of the per-tile BatchNorm statistics buffer written by ir2rgb_conv2d_fwd:
+ * stats_partial is [rows][2][Cout] fp32 (sum, sum of squares over the tile's pixels). */
+int ir2rgb_conv2d_stats_rows(const ir2rgb_conv_desc *d);
+
+/* Repack torch-layout fp32 weights (Conv2d [Cout,Cin,kh,kw]; ConvTranspose2d [Cin,Cout,kh,kw])
+ * into the K-contiguous half-precision layout the MFMA kernel streams. */
+int ir2rgb_conv2d_pack_weight(const ir2rgb_conv_desc *d, const float *w, void *wpacked, void *stream);
+
+/* y = act(conv(x) + bias); bias and stats_partial may be NULL.  x, wpacked, y 16-byte aligned. */
+int ir2rgb_conv2d_fwd(const ir2rgb_conv_desc *d, const void *x, const void *wpacked, const float *bias, void *y,
+                      float *stats_partial, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,14 @@ c_int, c_long, c_float, c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_float, 
 _pint = ctypes.POINTER(ctypes.c_int)
 P = c_void_p  # device pointer
 
+class ConvDesc(ctypes.Structure):
+    """ir2rgb_conv_desc of include/ir2rgb_hip.h."""
+    _fields_ = [(n, c_int) for n in ("N", "Hin", "Win", "Cin", "Hout", "Wout", "Cout", "kh", "kw", "stride", "pad",
+                                     "pad_mode", "transposed", "dtype", "act")]
+
+
+_pdesc = ctypes.POINTER(ConvDesc)
+
 # name -> (restype, argtypes)
 PROTOTYPES = {
     "ir2rgb_version": (ctypes.c_char_p, []),
@@ -26,6 +34,10 @@ PROTOTYPES = {
     "ir2rgb_channelnorm_fwd": (c_int, [P, P] + [c_int] * 5 + [P]),
     "ir2rgb_channelnorm_bwd": (c_int, [P, P, P, P] + [c_int] * 5 + [P]),
     "ir2rgb_warp_diff_norm_fwd": (c_int, [P] * 6 + [c_int] * 4 + [P]),
+    "ir2rgb_conv2d_packed_weight_elems": (c_long, [_pdesc]),
+    "ir2rgb_conv2d_stats_rows": (c_int, [_pdesc]),
+    "ir2rgb_conv2d_pack_weight": (c_int, [_pdesc, P, P, P]),
+    "ir2rgb_conv2d_fwd": (c_int, [_pdesc, P, P, P, P, P, P]),
 }
 
 _lib = None

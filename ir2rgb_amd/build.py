@@ -21,7 +21,7 @@ LIB = os.path.join(LIBDIR, "libir2rgb_hip.so")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 ARCH = "gfx950"
-CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+CXXFLAGS = ["-O3", "-std=c++20", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
             "-I", INCLUDE]
 
 

@@ -1,0 +1,85 @@
+"""Python face of the MFMA convolution entry points of libir2rgb_hip.so.
+
+Activations are NHWC half precision.  On the torch side an NHWC buffer is represented as a
+logical NCHW tensor in ``torch.channels_last`` memory format (same bytes), so tensors can be
+handed to/from ordinary torch code without copies.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc
+
+BF16, F16 = 1, 2
+_TORCH2DT = {torch.bfloat16: BF16, torch.float16: F16}
+PAD_ZERO, PAD_REFLECT = 0, 1
+ACT_NONE, ACT_LEAKY02 = 0, 1
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def out_size(h, k, stride, pad, transposed=False, output_padding=0):
+    if transposed:
+        return (h - 1) * stride - 2 * pad + k + output_padding
+    return (h + 2 * pad - k) // stride + 1
+
+
+def make_desc(x_shape, cout, k, stride, pad, pad_mode, dtype, transposed=False, output_padding=0, act=ACT_NONE):
+    """x_shape = (N, Cin, H, W) logical; k = int or (kh, kw)."""
+    n, cin, h, w = x_shape
+    kh, kw = (k, k) if isinstance(k, int) else k
+    ho = out_size(h, kh, stride, pad, transposed, output_padding)
+    wo = out_size(w, kw, stride, pad, transposed, output_padding)
+    return ConvDesc(n, h, w, cin, ho, wo, cout, kh, kw, stride, pad, pad_mode, int(transposed), _TORCH2DT[dtype], act)
+
+
+def is_nhwc(t):
+    return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)
+
+
+def empty_nhwc(n, c, h, w, dtype, device):
+    return torch.empty((n, c, h, w), dtype=dtype, device=device, memory_format=torch.channels_last)
+
+
+def pack_weight(desc, weight):
+    """weight: fp32 torch layout ([Cout,Cin,kh,kw], or [Cin,Cout,kh,kw] for transposed)."""
+    _lib.require_device(weight, dtype=torch.float32)
+    lib = _lib.lib()
+    n = lib.ir2rgb_conv2d_packed_weight_elems(ctypes.byref(desc))
+    if n < 0:
+        _lib.check(int(n), "conv2d_packed_weight_elems")
+    dt = torch.bfloat16 if desc.dtype == BF16 else torch.float16
+    packed = torch.empty(n, dtype=dt, device=weight.device)
+    with torch.cuda.device_of(weight):
+        rc = lib.ir2rgb_conv2d_pack_weight(ctypes.byref(desc), _p(weight), _p(packed), _lib.current_stream(weight))
+    _lib.check(rc, "conv2d_pack_weight")
+    return packed
+
+
+def stats_rows(desc):
+    r = _lib.lib().ir2rgb_conv2d_stats_rows(ctypes.byref(desc))
+    if r < 0:
+        _lib.check(r, "conv2d_stats_rows")
+    return r
+
+
+def conv2d_fwd(desc, x, wpacked, bias=None, want_stats=False, out=None):
+    """x: logical [N,Cin,H,W] channels_last half tensor.  Returns (y, stats_partial | None)."""
+    if not is_nhwc(x) or x.dtype not in _TORCH2DT or _TORCH2DT[x.dtype] != desc.dtype:
+        raise ValueError("conv2d_fwd: x must be a channels_last half tensor of the descriptor's dtype")
+    if tuple(x.shape) != (desc.N, desc.Cin, desc.Hin, desc.Win):
+        raise ValueError(f"conv2d_fwd: x shape {tuple(x.shape)} does not match the descriptor")
+    if not x.is_cuda:
+        raise ValueError("conv2d_fwd: GPU tensors only (no CPU fallback)")
+    y = out if out is not None else empty_nhwc(desc.N, desc.Cout, desc.Hout, desc.Wout, x.dtype, x.device)
+    stats = None
+    if want_stats:
+        stats = torch.empty((stats_rows(desc), 2, desc.Cout), dtype=torch.float32, device=x.device)
+    with torch.cuda.device_of(x):
+        rc = _lib.lib().ir2rgb_conv2d_fwd(ctypes.byref(desc), _p(x), _p(wpacked), _p(bias), _p(y), _p(stats),
+                                          _lib.current_stream(x))
+    _lib.check(rc, "conv2d_fwd")
+    return y, stats

@@ -1,0 +1,566 @@
+// conv_mfma.hip -- implicit-GEMM convolution on the gfx950 matrix cores.
+//
+// Covers every dense convolution of the vid2vid generator / discriminator bodies
+// (reference models/networks.py:141-171, :253-271, :556-580, :678-699): 3x3 stride 1 with
+// reflection padding (ResnetBlock), 3x3 / 4x4 stride 2 with zero padding, 4x4 stride 1, and
+// the 3x3 stride-2 transposed convolutions (as four sub-pixel convolutions), all with
+// Cin % 64 == 0.  In the reference each of these is a cuDNN call on NCHW fp32.
+//
+// Data layout (HBM)
+//   activations  X [N*Hin*Win][Cin], Y [N*Hout*Wout][Cout]   half precision (bf16 or f16), NHWC
+//   weights      Wp[class][Cout][Cin/64][ntaps][64]          half precision, K-contiguous rows;
+//                K index k = (cin_chunk, tap, cin_in_chunk): the 64-channel slice of the
+//                activations is re-used by all taps back-to-back (L2 / L1 hits for taps 2..n)
+//   bias         [Cout] fp32; stats_partial [rows][2][Cout] fp32 (sum, sum of squares of the
+//                fp32 conv outputs per pixel tile: the BatchNorm batch statistics, reduced
+//                deterministically by bn_finalize -- no atomics)
+//
+// GEMM view: D[cout][pixel] = sum_k Wp[cout][k] * Xg[pixel][k].  Couts are the MFMA M
+// dimension so that a lane ends up with 4 consecutive couts of one pixel (one 8-byte NHWC store).
+//
+// Workgroup = 512 threads = 8 waves (2 per SIMD), tile TC=128 couts x TP pixels, BK = 64.
+// Wave grid 2 (cout) x 4 (pixel); each wave owns 64 x TP/4 outputs as 4 x (TP/64)
+// v_mfma_f32_16x16x32 tiles.  Both operands are staged global -> LDS with 16-byte LDS-DMA
+// (global_load_lds_dwordx4; the per-lane SOURCE address carries the im2col gather -- reflection,
+// stride, sub-pixel phase -- and the XOR swizzle), three stages deep: loads for K-steps k+1
+// and k+2 are in flight while k is consumed; one raw s_barrier and one counted vmcnt per
+// K-step.  LDS rows are 128 B (64 halves); 16-byte slot s of row r holds chunk s ^ ((r>>1)&7),
+// which makes every ds_read_b128 fragment read bank-conflict free.
+//
+// Algorithmic flops = 2 * pixels * Cout * ntaps * Cin; roofline bound: MFMA.
+#include <type_traits>
+#include <utility>
+
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define IR2RGB_MAX_TAPS 49
+
+struct ConvGeom {
+    int N, Hin, Win, Cin;
+    int Hsub, Wsub;           // sub-grid of output positions computed by this launch
+    int Hout, Wout, Cout;
+    int s_in;                 // input coordinate  = sub * s_in  + d{y,x}[tap]
+    int s_out, off_y, off_x;  // output coordinate = sub * s_out + off
+    int ntaps, pad_mode;      // pad_mode 0: zeros outside, 1: reflect (no edge repeat)
+    int kchunks;              // Cin / 64
+    int act;                  // 0: none, 1: LeakyReLU(0.2) after bias
+    int stats_row0;           // first row of stats_partial written by this launch
+    // taps form an nty x ntx grid: tap (ty,tx) reads input offset (dy0 + ty*dys, dx0 + tx*dxs).
+    // Pure scalar arithmetic: no table load sits between the LDS-DMA issues of the K loop.
+    int ntx, dy0, dys, dx0, dxs;
+};
+
+__device__ __attribute__((aligned(128))) uint4 g_zero_page[8];  // 128 B of zeros: source of padded taps
+
+template <int DT> struct Half;
+template <> struct Half<IR2RGB_BF16> {
+    typedef bf16x8 frag;
+    static __device__ __forceinline__ f32x4 mfma(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ uint16_t cvt(float f) {
+        __bf16 h = (__bf16)f;
+        return __builtin_bit_cast(uint16_t, h);
+    }
+};
+template <> struct Half<IR2RGB_F16> {
+    typedef f16x8 frag;
+    static __device__ __forceinline__ f32x4 mfma(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ uint16_t cvt(float f) {
+        _Float16 h = (_Float16)f;
+        return __builtin_bit_cast(uint16_t, h);
+    }
+};
+
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+__device__ __forceinline__ void lds_dma16(const void *src, unsigned char *dst_wave_base) {
+    // 16 B per lane; LDS destination = wave-uniform base + lane * 16
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ int reflect(int v, int n) {
+    v = v < 0 ? -v : v;
+    return v >= n ? 2 * n - 2 - v : v;
+}
+
+// NTY x NTX > 0: the tap grid is a compile-time constant, the tap loop is fully unrolled and the
+// gather offsets of this thread's pixel rows are precomputed for every tap (PROWS*NTY*NTX
+// registers), so a K-step's staging costs ~3 VALU per row.  NTY == 0: runtime tap grid (any
+// shape), offsets recomputed per K-step.
+template <int DT, int TP, int NTY, int NTX>
+__global__ void __launch_bounds__(512, 2)
+conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Wp, const float *__restrict__ bias,
+                  uint16_t *__restrict__ Y, float *__restrict__ stats_partial, const ConvGeom g) {
+    constexpr int TC = 128;
+    constexpr int NI = TP / 64;            // 16-pixel MFMA tiles per wave along pixels
+    constexpr int WROWS = TC / 64;         // weight rows staged per thread per K-step
+    constexpr int PROWS = TP / 64;         // pixel rows staged per thread per K-step
+    constexpr int LOADS = WROWS + PROWS;   // LDS-DMA instructions per thread per K-step
+    constexpr int STAGE = (TC + TP) * 128; // bytes per stage
+    constexpr int NSTAGE = 3;
+    constexpr bool STATIC_TAPS = NTY > 0;
+    constexpr int NT = STATIC_TAPS ? NTY * NTX : 1;
+    typedef Half<DT> H;
+    typedef typename H::frag frag;
+
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTAGE * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave index as an SGPR: keeps the LDS-DMA destination (M0) provably wave-uniform, so hipcc
+    // emits no waterfall loop around global_load_lds.
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned P = (unsigned)g.N * g.Hsub * g.Wsub;  // host guarantees < 2^31
+    const unsigned HW = (unsigned)g.Hsub * g.Wsub;
+    const int npt = (int)((P + TP - 1) / TP), nct = (g.Cout + TC - 1) / TC;
+
+    // XCD-aware bijective remap: consecutive tile ids land on one XCD (blocks b, b+8, ... share
+    // an L2), and consecutive ids sweep the cout tiles of one pixel tile.
+    int tile;
+    {
+        const int nwg = npt * nct, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    const int pt = tile / nct, ct = tile - pt * nct;
+
+    // ---------------- per-thread staging roles ----------------
+    const int r8 = tid >> 3, slot = tid & 7;
+    const int chunk = slot ^ ((r8 >> 1) & 7);  // source chunk for this thread's LDS slot (swizzle)
+    const long Ktot = (long)g.kchunks * g.ntaps * 64;
+
+    const uint16_t *wsrc[WROWS];
+#pragma unroll
+    for (int i = 0; i < WROWS; ++i) {
+        int co = ct * TC + r8 + 64 * i;
+        co = co < g.Cout ? co : g.Cout - 1;  // clamp: rows past Cout are never stored
+        wsrc[i] = Wp + (long)co * Ktot + chunk * 8;
+    }
+    int psy[PROWS], psx[PROWS];  // sub * s_in: input coordinates before the tap offset
+    unsigned pbase[PROWS];       // n * Hin * Win (pixel index)
+#pragma unroll
+    for (int i = 0; i < PROWS; ++i) {
+        unsigned p = (unsigned)pt * TP + r8 + 64 * i;
+        const bool v = p < P;
+        p = v ? p : 0u;
+        unsigned n = p / HW, rem = p - n * HW;
+        unsigned sy = rem / (unsigned)g.Wsub;
+        // rows past the last pixel: zero padding -> parked outside the image (read the zero page);
+        // reflection -> pixel 0 (harmless, never stored)
+        psy[i] = v ? (int)sy * g.s_in : (g.pad_mode ? 0 : -(1 << 20));
+        psx[i] = (int)(rem - sy * g.Wsub) * g.s_in;
+        pbase[i] = n * (unsigned)(g.Hin * g.Win);
+    }
+    const uint16_t *zsrc = reinterpret_cast<const uint16_t *>(g_zero_page) + slot * 8;
+    const uint16_t *xsrc = X + chunk * 8;
+    unsigned char *const wave_dst = smem + wave * 1024;  // + stage*STAGE + 8192*i (+TC*128 for pixels)
+
+    // gather offset of (row i, tap) in units of 8 elements (16 B); 0xFFFFFFFF = padded with zeros
+    auto gather_off = [&](int i, int dy, int dx) -> unsigned {
+        int iy = psy[i] + dy, ix = psx[i] + dx;
+        const bool inb = ((unsigned)iy < (unsigned)g.Hin) & ((unsigned)ix < (unsigned)g.Win);
+        iy = g.pad_mode ? reflect(iy, g.Hin) : iy;
+        ix = g.pad_mode ? reflect(ix, g.Win) : ix;
+        const unsigned off = (pbase[i] + (unsigned)(iy * g.Win + ix)) * (unsigned)(g.Cin >> 3);
+        return (g.pad_mode || inb) ? off : 0xFFFFFFFFu;
+    };
+    auto dma_pixel = [&](unsigned off8, int cc, unsigned char *dst) {
+        const uint16_t *src = xsrc + (((unsigned long)off8) << 3) + cc * 64;
+        lds_dma16(off8 != 0xFFFFFFFFu ? src : zsrc, dst);
+    };
+
+    unsigned poff[STATIC_TAPS ? PROWS : 1][NT];
+    if constexpr (STATIC_TAPS) {
+#pragma unroll
+        for (int i = 0; i < PROWS; ++i)
+#pragma unroll
+            for (int ty = 0; ty < NTY; ++ty)
+#pragma unroll
+                for (int tx = 0; tx < NTX; ++tx)
+                    poff[i][ty * NTX + tx] = gather_off(i, g.dy0 + ty * g.dys, g.dx0 + tx * g.dxs);
+    }
+
+    // runtime-tap path: running (chunk, tap-row, tap-col) of the next K-step to be issued
+    int i_cc = 0, i_ty = 0, i_tx = 0, i_t = 0;
+    auto issue_weights = [&](int ks, unsigned char *dst) {
+#pragma unroll
+        for (int i = 0; i < WROWS; ++i) lds_dma16(wsrc[i] + (long)ks * 64, dst + 8192 * i);
+    };
+    auto issue_dynamic = [&](int ks, int buf) {
+        unsigned char *dst = wave_dst + buf * STAGE;
+        issue_weights(ks, dst);
+        const int dy = g.dy0 + i_ty * g.dys, dx = g.dx0 + i_tx * g.dxs;
+#pragma unroll
+        for (int i = 0; i < PROWS; ++i) dma_pixel(gather_off(i, dy, dx), i_cc, dst + TC * 128 + 8192 * i);
+        if (++i_tx == g.ntx) { i_tx = 0; ++i_ty; }
+        if (++i_t == g.ntaps) { i_t = 0; i_ty = 0; i_tx = 0; ++i_cc; }
+    };
+
+    // ---------------- per-wave compute roles ----------------
+    const int wc = wave & 1, wp = wave >> 1;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int sw0 = (lq ^ (l15 >> 1)) << 4;  // byte offset of k-group lq      in a swizzled row
+    const int sw1 = sw0 ^ 64;                // byte offset of k-group lq + 4
+    const int offA = (wc * 64 + l15) * 128;                  // + mi * 2048
+    const int offB = TC * 128 + (wp * (TP / 4) + l15) * 128; // + ni * 2048
+
+    f32x4 acc[4][NI];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.kchunks * g.ntaps;
+
+    auto wait_stage = [&](int ks) {
+        // stage ks has landed for THIS wave once all but the newest LOADS (stage ks+1) are done
+        if (ks + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+        else             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // ... and for every wave; also: everyone is done reading stage ks-1
+    };
+    auto compute = [&](int buf) {
+        const unsigned char *s = smem + buf * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int sw = kk ? sw1 : sw0;
+            frag a[4], b[NI];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) a[mi] = *reinterpret_cast<const frag *>(s + offA + mi * 2048 + sw);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const frag *>(s + offB + ni * 2048 + sw);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = H::mfma(a[mi], b[ni], acc[mi][ni]);
+        }
+    };
+
+    if constexpr (STATIC_TAPS) {
+        // K-step ks = cc*NT + t.  Prologue: stages 0 and 1.
+        auto issue_static = [&](int ks, int cc, auto tconst, int buf) {
+            constexpr int t = decltype(tconst)::value;
+            unsigned char *dst = wave_dst + buf * STAGE;
+            issue_weights(ks, dst);
+#pragma unroll
+            for (int i = 0; i < PROWS; ++i) dma_pixel(poff[i][t], cc, dst + TC * 128 + 8192 * i);
+        };
+        issue_static(0, 0, std::integral_constant<int, 0>{}, 0);
+        if (nk > 1) issue_static(1, NT > 1 ? 0 : 1, std::integral_constant<int, (NT > 1 ? 1 : 0)>{}, 1);
+        int ks = 0, buf = 0;
+        for (int cc = 0; cc < g.kchunks; ++cc) {
+            // unrolled over the taps: t is a compile-time constant inside
+            auto body = [&](auto tconst) {
+                constexpr int t = decltype(tconst)::value;
+                wait_stage(ks);
+                if (ks + 2 < nk) {
+                    constexpr int t2 = (t + 2) % NT;
+                    const int cc2 = cc + (t + 2) / NT;
+                    int b2 = buf + 2; b2 = b2 >= NSTAGE ? b2 - NSTAGE : b2;
+                    issue_static(ks + 2, cc2, std::integral_constant<int, t2>{}, b2);
+                }
+                compute(buf);
+                ++ks;
+                buf = buf + 1 == NSTAGE ? 0 : buf + 1;
+            };
+            [&]<int... Ts>(std::integer_sequence<int, Ts...>) { (body(std::integral_constant<int, Ts>{}), ...); }
+            (std::make_integer_sequence<int, NT>{});
+        }
+    } else {
+        issue_dynamic(0, 0);
+        if (nk > 1) issue_dynamic(1, 1);
+        int buf = 0;
+        for (int ks = 0; ks < nk; ++ks) {
+            wait_stage(ks);
+            if (ks + 2 < nk) {
+                int b2 = buf + 2; b2 = b2 >= NSTAGE ? b2 - NSTAGE : b2;
+                issue_dynamic(ks + 2, b2);
+            }
+            compute(buf);
+            buf = buf + 1 == NSTAGE ? 0 : buf + 1;
+        }
+    }
+
+    // ---------------- epilogue: bias, activation, BN statistics, NHWC store ----------------
+    // acc[mi][ni][r]: cout = ct*TC + wc*64 + mi*16 + lq*4 + r ; pixel = pt*TP + wp*(TP/4) + ni*16 + l15
+    __builtin_amdgcn_s_barrier();  // all waves are past their last LDS read: smem is reusable
+    float *red = reinterpret_cast<float *>(smem);  // [4 wp][TC][2]
+    const int co_base = ct * TC + wc * 64 + lq * 4;
+    long opix[NI];
+    bool oval[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        unsigned p = (unsigned)pt * TP + wp * (TP / 4) + ni * 16 + l15;
+        oval[ni] = p < P;
+        p = oval[ni] ? p : 0u;
+        unsigned n = p / HW, rem = p - n * HW;
+        unsigned sy = rem / (unsigned)g.Wsub, sx = rem - sy * g.Wsub;
+        opix[ni] = ((long)n * g.Hout + (sy * g.s_out + g.off_y)) * g.Wout + (sx * g.s_out + g.off_x);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int co = co_base + mi * 16;
+        float bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[r] = (bias != nullptr && co + r < g.Cout) ? bias[co + r] : 0.f;
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[mi][ni][r] + bv[r];
+                if (g.act == 1) v[r] = v[r] > 0.f ? v[r] : 0.2f * v[r];
+                if (oval[ni]) { s1[r] += v[r]; s2[r] += v[r] * v[r]; }
+            }
+            if (oval[ni]) {
+                uint16_t *dst = Y + opix[ni] * g.Cout + co;
+                if (co + 3 < g.Cout) {
+                    uint2 pk;
+                    pk.x = (uint32_t)H::cvt(v[0]) | ((uint32_t)H::cvt(v[1]) << 16);
+                    pk.y = (uint32_t)H::cvt(v[2]) | ((uint32_t)H::cvt(v[3]) << 16);
+                    *reinterpret_cast<uint2 *>(dst) = pk;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < g.Cout) dst[r] = H::cvt(v[r]);
+                }
+            }
+        }
+        if (stats_partial != nullptr) {
+            // sum over the 16 pixels held by lanes l15 = 0..15 of this quarter-wave
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) {
+                    s1[r] += __shfl_xor(s1[r], m, 64);
+                    s2[r] += __shfl_xor(s2[r], m, 64);
+                }
+            }
+            if (l15 == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int cl = wc * 64 + mi * 16 + lq * 4 + r;  // cout within the tile
+                    red[(wp * TC + cl) * 2 + 0] = s1[r];
+                    red[(wp * TC + cl) * 2 + 1] = s2[r];
+                }
+            }
+        }
+    }
+    if (stats_partial != nullptr) {
+        __syncthreads();
+        if (tid < TC * 2) {
+            const int cl = tid >> 1, which = tid & 1, co = ct * TC + cl;
+            if (co < g.Cout) {
+                float t = red[(0 * TC + cl) * 2 + which] + red[(1 * TC + cl) * 2 + which] +
+                          red[(2 * TC + cl) * 2 + which] + red[(3 * TC + cl) * 2 + which];
+                stats_partial[((long)(g.stats_row0 + pt) * 2 + which) * g.Cout + co] = t;
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// weight packing: torch layout (fp32) -> Wp[class][Cout][Cin/64][ntaps][64] (half)
+//   Conv2d          weight [Cout][Cin][kh][kw]
+//   ConvTranspose2d weight [Cin][Cout][kh][kw]
+// ----------------------------------------------------------------------------------------
+struct PackGeom {
+    int Cout, Cin, kh, kw, transposed;
+    int ntaps;
+    signed char ky[IR2RGB_MAX_TAPS], kx[IR2RGB_MAX_TAPS];
+};
+
+template <int DT>
+__global__ void __launch_bounds__(256)
+pack_weight_kernel(const float *__restrict__ w, uint16_t *__restrict__ wp, const PackGeom g, long total) {
+    const int kchunks = g.Cin / 64;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r = i;
+        int c64 = (int)(r & 63); r >>= 6;
+        int tap = (int)(r % g.ntaps); r /= g.ntaps;
+        int cc = (int)(r % kchunks);
+        int co = (int)(r / kchunks);
+        int ci = cc * 64 + c64;
+        long src = g.transposed ? (((long)ci * g.Cout + co) * g.kh + g.ky[tap]) * g.kw + g.kx[tap]
+                                : (((long)co * g.Cin + ci) * g.kh + g.ky[tap]) * g.kw + g.kx[tap];
+        wp[i] = Half<DT>::cvt(w[src]);
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// host side
+// ----------------------------------------------------------------------------------------
+struct ClassPlan {
+    ConvGeom geom;
+    PackGeom pack;
+    long w_offset;  // element offset of this class in the packed weight buffer
+    int npt;        // pixel tiles (TP chosen at plan time)
+};
+
+static int tile_pixels(long P, int Cout) {
+    // aim for >= 256 workgroups (one per CU); TP in {256, 128, 64}
+    const long nct = (Cout + 127) / 128;
+    if (((P + 255) / 256) * nct >= 256) return 256;
+    if (((P + 127) / 128) * nct >= 256) return 128;
+    return 64;
+}
+
+// Builds the launch plan(s) for one convolution; returns the number of classes or < 0.
+static int make_plan(const ir2rgb_conv_desc *d, ClassPlan plans[4]) {
+    if (!d || d->N < 1 || d->Cin < 64 || (d->Cin % 64) || d->Cout < 1 || d->kh < 1 || d->kw < 1 ||
+        d->kh * d->kw > IR2RGB_MAX_TAPS || d->stride < 1 || d->pad < 0)
+        return IR2RGB_EINVAL;
+    if (d->dtype != IR2RGB_BF16 && d->dtype != IR2RGB_F16) return IR2RGB_ENOSUP;
+    int ncls = 0;
+    long woff = 0;
+    int row0 = 0;
+    if (!d->transposed) {
+        int Ho = (d->Hin + 2 * d->pad - d->kh) / d->stride + 1, Wo = (d->Win + 2 * d->pad - d->kw) / d->stride + 1;
+        if (Ho != d->Hout || Wo != d->Wout || Ho < 1 || Wo < 1) return IR2RGB_EINVAL;
+        if (d->pad_mode == 1 && (d->pad >= d->Hin || d->pad >= d->Win)) return IR2RGB_EINVAL;
+        ClassPlan &c = plans[0];
+        ConvGeom &g = c.geom;
+        g = ConvGeom{};
+        g.N = d->N; g.Hin = d->Hin; g.Win = d->Win; g.Cin = d->Cin;
+        g.Hsub = Ho; g.Wsub = Wo; g.Hout = Ho; g.Wout = Wo; g.Cout = d->Cout;
+        g.s_in = d->stride; g.s_out = 1; g.off_y = g.off_x = 0;
+        g.ntaps = d->kh * d->kw; g.pad_mode = d->pad_mode; g.kchunks = d->Cin / 64; g.act = d->act;
+        c.pack = PackGeom{};
+        c.pack.Cout = d->Cout; c.pack.Cin = d->Cin; c.pack.kh = d->kh; c.pack.kw = d->kw; c.pack.transposed = 0;
+        c.pack.ntaps = g.ntaps;
+        g.ntx = d->kw; g.dy0 = -d->pad; g.dys = 1; g.dx0 = -d->pad; g.dxs = 1;
+        for (int ky = 0, t = 0; ky < d->kh; ++ky)
+            for (int kx = 0; kx < d->kw; ++kx, ++t) {
+                c.pack.ky[t] = (signed char)ky; c.pack.kx[t] = (signed char)kx;
+            }
+        c.w_offset = 0;
+        ncls = 1;
+    } else {
+        // stride-2 transposed convolution as 4 sub-pixel (output parity) classes:
+        //   oy = 2*iy - pad + ky  ->  for oy = 2*sy + a: ky = (a + pad) mod 2 (+2j), iy = sy + (a + pad - ky)/2
+        if (d->stride != 2 || d->pad_mode != 0) return IR2RGB_ENOSUP;
+        if ((d->Hout & 1) || (d->Wout & 1) || d->Hout / 2 < 1) return IR2RGB_EINVAL;
+        int Hfull = (d->Hin - 1) * 2 - 2 * d->pad + d->kh, Wfull = (d->Win - 1) * 2 - 2 * d->pad + d->kw;
+        if (d->Hout < Hfull || d->Hout > Hfull + 1 || d->Wout < Wfull || d->Wout > Wfull + 1) return IR2RGB_EINVAL;
+        for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b) {
+                ClassPlan &c = plans[ncls];
+                ConvGeom &g = c.geom;
+                g = ConvGeom{};
+                g.N = d->N; g.Hin = d->Hin; g.Win = d->Win; g.Cin = d->Cin;
+                g.Hsub = d->Hout / 2; g.Wsub = d->Wout / 2; g.Hout = d->Hout; g.Wout = d->Wout; g.Cout = d->Cout;
+                g.s_in = 1; g.s_out = 2; g.off_y = a; g.off_x = b;
+                g.pad_mode = 0; g.kchunks = d->Cin / 64; g.act = d->act;
+                c.pack = PackGeom{};
+                c.pack.Cout = d->Cout; c.pack.Cin = d->Cin; c.pack.kh = d->kh; c.pack.kw = d->kw; c.pack.transposed = 1;
+                int t = 0, ntx = 0;
+                const int ky0 = (a + d->pad) & 1, kx0 = (b + d->pad) & 1;
+                for (int ky = ky0; ky < d->kh; ky += 2) {
+                    ntx = 0;
+                    for (int kx = kx0; kx < d->kw; kx += 2, ++t, ++ntx) {
+                        c.pack.ky[t] = (signed char)ky; c.pack.kx[t] = (signed char)kx;
+                    }
+                }
+                if (t == 0) return IR2RGB_ENOSUP;
+                // iy = sy + (a + pad - ky)/2 with ky = ky0 + 2*ty  (numerator even by construction)
+                g.ntx = ntx; g.dy0 = (a + d->pad - ky0) / 2; g.dys = -1; g.dx0 = (b + d->pad - kx0) / 2; g.dxs = -1;
+                g.ntaps = t; c.pack.ntaps = t;
+                c.w_offset = woff;
+                woff += (long)d->Cout * d->Cin * t;
+                ++ncls;
+            }
+    }
+    if ((long)d->N * d->Hin * d->Win >= (1L << 31) || (long)d->N * d->Hout * d->Wout >= (1L << 31) ||
+        (long)d->N * d->Hin * d->Win * (d->Cin / 8) >= 0xFFFFFFFFL)
+        return IR2RGB_EINVAL;
+    for (int i = 0; i < ncls; ++i) {
+        ConvGeom &g = plans[i].geom;
+        long P = (long)g.N * g.Hsub * g.Wsub;
+        int tp = tile_pixels(P, g.Cout);
+        plans[i].npt = (int)((P + tp - 1) / tp);
+        g.stats_row0 = row0;
+        row0 += plans[i].npt;
+    }
+    return ncls;
+}
+
+extern "C" long ir2rgb_conv2d_packed_weight_elems(const ir2rgb_conv_desc *d) {
+    ClassPlan plans[4];
+    int n = make_plan(d, plans);
+    if (n < 0) return n;
+    long e = 0;
+    for (int i = 0; i < n; ++i) e += (long)d->Cout * d->Cin * plans[i].geom.ntaps;
+    return e;
+}
+
+extern "C" int ir2rgb_conv2d_stats_rows(const ir2rgb_conv_desc *d) {
+    ClassPlan plans[4];
+    int n = make_plan(d, plans);
+    if (n < 0) return n;
+    int rows = 0;
+    for (int i = 0; i < n; ++i) rows += plans[i].npt;
+    return rows;
+}
+
+extern "C" int ir2rgb_conv2d_pack_weight(const ir2rgb_conv_desc *d, const float *w, void *wpacked, void *stream) {
+    ClassPlan plans[4];
+    int n = make_plan(d, plans);
+    if (n < 0) return n;
+    for (int i = 0; i < n; ++i) {
+        long total = (long)d->Cout * d->Cin * plans[i].geom.ntaps;
+        uint16_t *dst = reinterpret_cast<uint16_t *>(wpacked) + plans[i].w_offset;
+        int grid = stream_grid(total, 256);
+        if (d->dtype == IR2RGB_BF16)
+            pack_weight_kernel<IR2RGB_BF16><<<grid, 256, 0, as_stream(stream)>>>(w, dst, plans[i].pack, total);
+        else
+            pack_weight_kernel<IR2RGB_F16><<<grid, 256, 0, as_stream(stream)>>>(w, dst, plans[i].pack, total);
+    }
+    return ir2rgb_launch_status();
+}
+
+template <int DT, int NTY, int NTX>
+static void launch_conv_taps(const ClassPlan &c, int tp, unsigned grid, const uint16_t *x, const uint16_t *wp,
+                             const float *bias, uint16_t *y, float *stats, hipStream_t s) {
+    const ConvGeom &g = c.geom;
+    switch (tp) {
+        case 256: conv_igemm_kernel<DT, 256, NTY, NTX><<<grid, 512, 0, s>>>(x, wp, bias, y, stats, g); break;
+        case 128: conv_igemm_kernel<DT, 128, NTY, NTX><<<grid, 512, 0, s>>>(x, wp, bias, y, stats, g); break;
+        default:  conv_igemm_kernel<DT, 64, NTY, NTX><<<grid, 512, 0, s>>>(x, wp, bias, y, stats, g); break;
+    }
+}
+
+template <int DT>
+static void launch_conv(const ClassPlan &c, const uint16_t *x, const uint16_t *wp, const float *bias, uint16_t *y,
+                        float *stats, hipStream_t s) {
+    const ConvGeom &g = c.geom;
+    const long P = (long)g.N * g.Hsub * g.Wsub;
+    const int tp = tile_pixels(P, g.Cout);
+    const int nct = (g.Cout + 127) / 128;
+    const unsigned grid = (unsigned)(c.npt * nct);
+    const int nty = g.ntaps / g.ntx;
+    if (nty == 3 && g.ntx == 3)      launch_conv_taps<DT, 3, 3>(c, tp, grid, x, wp, bias, y, stats, s);
+    else if (nty == 4 && g.ntx == 4) launch_conv_taps<DT, 4, 4>(c, tp, grid, x, wp, bias, y, stats, s);
+    else                             launch_conv_taps<DT, 0, 0>(c, tp, grid, x, wp, bias, y, stats, s);
+}
+
+extern "C" int ir2rgb_conv2d_fwd(const ir2rgb_conv_desc *d, const void *x, const void *wpacked, const float *bias,
+                                 void *y, float *stats_partial, void *stream) {
+    ClassPlan plans[4];
+    int n = make_plan(d, plans);
+    if (n < 0) return n;
+    if ((((uintptr_t)x | (uintptr_t)wpacked | (uintptr_t)y) & 15) != 0) return IR2RGB_EALIGN;
+    for (int i = 0; i < n; ++i) {
+        const uint16_t *wp = reinterpret_cast<const uint16_t *>(wpacked) + plans[i].w_offset;
+        if (d->dtype == IR2RGB_BF16)
+            launch_conv<IR2RGB_BF16>(plans[i], (const uint16_t *)x, wp, bias, (uint16_t *)y, stats_partial, as_stream(stream));
+        else
+            launch_conv<IR2RGB_F16>(plans[i], (const uint16_t *)x, wp, bias, (uint16_t *)y, stats_partial, as_stream(stream));
+    }
+    return ir2rgb_launch_status();
+}

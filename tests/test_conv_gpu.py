@@ -1,0 +1,118 @@
+"""GPU parity tests of the MFMA implicit-GEMM convolution (through the C ABI) against torch
+fp32 convolutions evaluated on the SAME half-rounded inputs and weights, so that the only
+differences are fp32 accumulation order and the final rounding of the output to half.
+
+Tolerance: |delta| <= 2^-8 * |ref| + 1e-2 * rms(ref) for bf16 (one bf16 ulp of the output plus
+accumulation noise), 2^-11 * |ref| + 2e-3 * rms(ref) for f16.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_and_run(dev, dtype, N, Cin, H, W, Cout, k, stride, pad, pad_mode, transposed=False, opad=0, act=0, seed=0):
+    from ir2rgb_amd import conv as C
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(N, Cin, H, W, generator=g).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    wshape = (Cin, Cout, k, k) if transposed else (Cout, Cin, k, k)
+    w = (torch.randn(wshape, generator=g) * (1.0 / np.sqrt(Cin * k * k))).to(dev)
+    b = torch.randn(Cout, generator=g).to(dev)
+    desc = C.make_desc(x.shape, Cout, k, stride, pad, pad_mode, dtype, transposed, opad, act)
+    wp = C.pack_weight(desc, w)
+    y, stats = C.conv2d_fwd(desc, x, wp, b, want_stats=True)
+    xr, wr = x.float(), w.to(dtype).float()
+    if transposed:
+        ref = F.conv_transpose2d(xr, wr, b, stride=stride, padding=pad, output_padding=opad)
+    else:
+        if pad_mode == 1 and pad > 0:
+            xr = F.pad(xr, (pad,) * 4, mode="reflect")
+            ref = F.conv2d(xr, wr, b, stride=stride)
+        else:
+            ref = F.conv2d(xr, wr, b, stride=stride, padding=pad)
+    if act == 1:
+        ref = F.leaky_relu(ref, 0.2)
+    return y, stats, ref
+
+
+def _check(y, stats, ref, dtype):
+    assert y.shape == ref.shape
+    yf = y.float()
+    rms = ref.pow(2).mean().sqrt().item()
+    rel, ab = (2.0 ** -8, 1e-2) if dtype == torch.bfloat16 else (2.0 ** -11, 2e-3)
+    err = (yf - ref).abs()
+    bound = rel * ref.abs() + ab * rms
+    bad = (err > bound).sum().item()
+    assert bad == 0, f"{bad} elements out of tolerance; max err {err.max().item():.4g}, rms {rms:.4g}"
+    # BN statistics: per-channel sum / sum of squares over all pixels of the fp32 result
+    s = stats.sum(0)
+    n = ref.numel() / ref.shape[1]
+    torch.testing.assert_close(s[0] / n, ref.mean((0, 2, 3)), atol=2e-3 * max(rms, 1e-3), rtol=1e-3)
+    torch.testing.assert_close(s[1] / n, ref.pow(2).mean((0, 2, 3)), atol=2e-3 * max(rms * rms, 1e-3), rtol=2e-3)
+
+
+CASES = [
+    # N, Cin, H, W, Cout, k, stride, pad, pad_mode, transposed, opad
+    (1, 64, 16, 32, 128, 3, 1, 1, 1, False, 0),      # ResnetBlock-style reflect 3x3, TP=64
+    (1, 128, 32, 64, 128, 3, 1, 1, 1, False, 0),     # TP=64, two K chunks
+    (2, 64, 24, 40, 192, 3, 1, 1, 1, False, 0),      # batch 2, Cout not a multiple of 128
+    (1, 64, 33, 47, 64, 3, 2, 1, 0, False, 0),       # stride 2 zero pad, odd sizes, Cout 64
+    (1, 64, 20, 36, 128, 4, 2, 2, 0, False, 0),      # discriminator 4x4 s2 p2
+    (1, 128, 17, 19, 8, 4, 1, 2, 0, False, 0),       # discriminator 4x4 s1 p2, tiny Cout
+    (1, 128, 16, 24, 64, 3, 2, 1, 0, True, 1),       # ConvTranspose 3x3 s2 p1 op1
+    (1, 64, 9, 13, 32, 4, 2, 1, 0, True, 0),         # ConvTranspose 4x4 s2 p1 (FlowNet deconv)
+    (1, 64, 64, 128, 128, 3, 1, 1, 1, False, 0),     # 8192 pixels -> TP=128 path
+    (1, 64, 128, 256, 128, 3, 1, 1, 1, False, 0),    # 32768 pixels -> TP=256 path
+    (1, 64, 12, 20, 130, 1, 1, 0, 0, False, 0),      # 1x1 (runtime tap path), ragged Cout
+    (1, 64, 40, 24, 128, 7, 1, 3, 1, False, 0),      # 7x7 reflect (runtime tap path, 49 taps)
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", CASES)
+def test_conv_vs_torch(dev, dtype, case):
+    N, Cin, H, W, Cout, k, s, p, pm, tr, op = case
+    y, stats, ref = _ref_and_run(dev, dtype, N, Cin, H, W, Cout, k, s, p, pm, tr, op, seed=Cin + H)
+    _check(y, stats, ref, dtype)
+
+
+def test_conv_fused_leaky(dev):
+    y, stats, ref = _ref_and_run(dev, torch.bfloat16, 1, 64, 20, 36, 64, 4, 2, 2, 0, act=1)
+    _check(y, stats, ref, torch.bfloat16)
+
+
+def test_conv_exact_integers(dev):
+    """Small-integer data is exact in bf16 and in fp32 accumulation: bit-exact against torch.
+    Asymmetric data catches transposed fragment maps."""
+    from ir2rgb_amd import conv as C
+    g = torch.Generator(device="cpu").manual_seed(3)
+    x = torch.randint(-2, 3, (1, 64, 10, 12), generator=g).float().to(dev).to(torch.bfloat16)
+    x = x.contiguous(memory_format=torch.channels_last)
+    w = torch.randint(-2, 3, (128, 64, 3, 3), generator=g).float().to(dev)
+    desc = C.make_desc(x.shape, 128, 3, 1, 1, 1, torch.bfloat16)
+    y, _ = C.conv2d_fwd(desc, x, C.pack_weight(desc, w))
+    ref = F.conv2d(F.pad(x.float(), (1,) * 4, mode="reflect"), w)
+    assert ref.abs().max() < 256  # exactly representable in bf16? integers up to 256 are
+    assert torch.equal(y.float(), ref)
+
+
+def test_hot_shape_linearity(dev):
+    """Full-size bottleneck conv of the 512x1024 generator (1024->1024 @64x128): linearity in the
+    input and agreement with torch on a random subset of output channels."""
+    from ir2rgb_amd import conv as C
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x1 = torch.randn(1, 1024, 64, 128, generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(1024, 1024, 3, 3, generator=g) * 0.01).to(dev)
+    desc = C.make_desc(x1.shape, 1024, 3, 1, 1, 1, torch.bfloat16)
+    wp = C.pack_weight(desc, w)
+    y1, stats = C.conv2d_fwd(desc, x1, wp, want_stats=True)
+    y2, _ = C.conv2d_fwd(desc, (x1 * 2).contiguous(memory_format=torch.channels_last), wp)
+    assert torch.equal(y2.float(), y1.float() * 2)  # scaling by 2 is exact in bf16/fp32
+    idx = torch.tensor([0, 1, 127, 128, 511, 777, 1023], device=dev)
+    ref = F.conv2d(F.pad(x1.float(), (1,) * 4, mode="reflect"), w[idx].to(torch.bfloat16).float())
+    got = y1.float()[:, idx]
+    rms = ref.pow(2).mean().sqrt().item()
+    assert ((got - ref).abs() <= 2.0 ** -8 * ref.abs() + 1e-2 * rms).all()
+    torch.testing.assert_close(stats.sum(0)[0][idx] / 8192, ref.mean((0, 2, 3)), atol=2e-3 * rms, rtol=1e-3)
