@@ -113,11 +113,12 @@ int ir2rgb_warp_diff_norm_fwd(const float *img1, const float *img2, const float 
 typedef struct ir2rgb_conv_desc {
     int N, Hin, Win, Cin;   /* input  [N,Hin,Win,Cin]  NHWC, Cin % 64 == 0 */
     int Hout, Wout, Cout;   /* output [N,Hout,Wout,Cout] NHWC              */
-    int kh, kw, stride, pad;
+    int kh, kw, stride_h, stride_w, pad_h, pad_w;
     int pad_mode;           /* 0: zero padding, 1: reflection padding (nn.ReflectionPad2d) */
     int transposed;         /* 0: Conv2d, 1: ConvTranspose2d (stride 2; Hout/Wout carry output_padding) */
     int dtype;              /* IR2RGB_BF16 or IR2RGB_F16: activations and packed weights */
     int act;                /* fused after bias: 0 none, 1 LeakyReLU(0.2) */
+    int out_f32;            /* 0: y is half NHWC, 1: y is fp32 NHWC (head convolutions) */
 } ir2rgb_conv_desc;
 
 /* Number of half elements of the packed weight buffer for this convolution (< 0: error). */
@@ -134,6 +135,47 @@ int ir2rgb_conv2d_pack_weight(const ir2rgb_conv_desc *d, const float *w, void *w
 /* y = act(conv(x) + bias); bias and stats_partial may be NULL.  x, wpacked, y 16-byte aligned. */
 int ir2rgb_conv2d_fwd(const ir2rgb_conv_desc *d, const void *x, const void *wpacked, const float *bias, void *y,
                       float *stats_partial, void *stream);
+
+/* Training-mode BatchNorm2d statistics (reference norm_layer = nn.BatchNorm2d, networks.py:41-48).
+ * Reduces the [rows][2][C] partial sums written by ir2rgb_conv2d_fwd over `count` pixels into
+ * scale = gamma*invstd and shift = beta - mean*scale, and updates running_mean / running_var
+ * in place (momentum form of torch: new = (1-m)*old + m*batch, unbiased variance).  gamma, beta,
+ * running_*, mean_out, invstd_out may be NULL. */
+int ir2rgb_bn_finalize(const float *stats_partial, int rows, int C, long count, const float *gamma,
+                       const float *beta, float *running_mean, float *running_var, float momentum, float eps,
+                       float *scale, float *shift, float *mean_out, float *invstd_out, void *stream);
+
+/* y = act(x*scale[c] + shift[c]) + res1 + res2 on NHWC half tensors of npix pixels x C channels
+ * (C % 8 == 0).  act: 0 none, 1 ReLU, 2 LeakyReLU(0.2).  res1/res2 may be NULL; y may alias x.
+ * Covers norm+activation (networks.py:141-171, :253-271, :678-699), the ResnetBlock skip
+ * (:585) and the encoder sum (:192, :290-291). */
+int ir2rgb_bn_apply(const void *x, const float *scale, const float *shift, const void *res1, const void *res2,
+                    void *y, long npix, int C, int act, int dtype, void *stream);
+
+/* Layout converters between the reference's NCHW fp32 tensors and NHWC half. */
+int ir2rgb_nchw_f32_to_nhwc_half(const float *in, void *out, int N, int C, int H, int W, int dtype, void *stream);
+int ir2rgb_nhwc_half_to_nchw_f32(const void *in, float *out, int N, int C, int H, int W, int dtype, void *stream);
+
+/* x-direction im2col of a small-channel NCHW fp32 image into 64-channel NHWC half:
+ *   out[n][y][ox][ci*KW + kx] = in[n][ci][y][pad(ox*stride_w + kx - pad_w)],  Cin*KW <= 64.
+ * Turns the first layers (ReflectionPad2d(3)+Conv7x7 on 9/6 channels, networks.py:141,:150,
+ * :253-255; Conv4x4 s2 p2 on 6/13 channels, :680) into KH x 1 convolutions for the MFMA kernel. */
+int ir2rgb_xexpand(const float *in, void *out, int N, int Cin, int H, int W, int Wout, int KW, int stride_w,
+                   int pad_w, int pad_mode, int dtype, void *stream);
+
+/* Finish of a separable head: T [N,H,W,CT] fp32 holds, in channel co*KH+ky, the horizontal
+ * part of a KHxKW convolution; out[n][co][y][x] = f(sum_ky T[n][refl(y+ky-pad)][x][co*KH+ky] + bias[co]).
+ * acts packs one nibble per output channel: 0 -> linear * mul, 1 -> tanh, 2 -> sigmoid.
+ * (ReflectionPad2d(3)+Conv7x7 heads with tanh / *20 / sigmoid, networks.py:166,:170-171,:200-201) */
+int ir2rgb_head_finish(const float *T, const float *bias, float *out, int N, int H, int W, int Cout, int KH,
+                       int CT, int pad_h, unsigned acts, float mul, void *stream);
+
+/* Temporal blend of the generator (networks.py:89-100, :207-209):
+ *   warp = grid_sample(prev, grid + flow_normalised, bilinear, border)   [align_corners quirk kept]
+ *   out  = raw * w + warp * (1 - w)
+ * raw [N,3,H,W], prev [N,Cp,H,W] (its LAST 3 channels are warped), flow [N,2,H,W], w [N,1,H,W]. */
+int ir2rgb_warp_blend_fwd(const float *raw, const float *prev, const float *flow, const float *w, float *out,
+                          float *warp_out, int N, int Cp, int H, int W, void *stream);
 
 #ifdef __cplusplus
 }

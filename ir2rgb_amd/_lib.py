@@ -17,8 +17,8 @@ P = c_void_p  # device pointer
 
 class ConvDesc(ctypes.Structure):
     """ir2rgb_conv_desc of include/ir2rgb_hip.h."""
-    _fields_ = [(n, c_int) for n in ("N", "Hin", "Win", "Cin", "Hout", "Wout", "Cout", "kh", "kw", "stride", "pad",
-                                     "pad_mode", "transposed", "dtype", "act")]
+    _fields_ = [(n, c_int) for n in ("N", "Hin", "Win", "Cin", "Hout", "Wout", "Cout", "kh", "kw", "stride_h", "stride_w",
+                                     "pad_h", "pad_w", "pad_mode", "transposed", "dtype", "act", "out_f32")]
 
 
 _pdesc = ctypes.POINTER(ConvDesc)
@@ -38,6 +38,13 @@ PROTOTYPES = {
     "ir2rgb_conv2d_stats_rows": (c_int, [_pdesc]),
     "ir2rgb_conv2d_pack_weight": (c_int, [_pdesc, P, P, P]),
     "ir2rgb_conv2d_fwd": (c_int, [_pdesc, P, P, P, P, P, P]),
+    "ir2rgb_bn_finalize": (c_int, [P, c_int, c_int, c_long, P, P, P, P, c_float, c_float, P, P, P, P, P]),
+    "ir2rgb_bn_apply": (c_int, [P, P, P, P, P, P, c_long, c_int, c_int, c_int, P]),
+    "ir2rgb_nchw_f32_to_nhwc_half": (c_int, [P, P] + [c_int] * 5 + [P]),
+    "ir2rgb_nhwc_half_to_nchw_f32": (c_int, [P, P] + [c_int] * 5 + [P]),
+    "ir2rgb_xexpand": (c_int, [P, P] + [c_int] * 10 + [P]),
+    "ir2rgb_head_finish": (c_int, [P, P, P] + [c_int] * 7 + [ctypes.c_uint, c_float, P]),
+    "ir2rgb_warp_blend_fwd": (c_int, [P] * 6 + [c_int] * 4 + [P]),
 }
 
 _lib = None

@@ -27,13 +27,19 @@ def out_size(h, k, stride, pad, transposed=False, output_padding=0):
     return (h + 2 * pad - k) // stride + 1
 
 
-def make_desc(x_shape, cout, k, stride, pad, pad_mode, dtype, transposed=False, output_padding=0, act=ACT_NONE):
-    """x_shape = (N, Cin, H, W) logical; k = int or (kh, kw)."""
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+def make_desc(x_shape, cout, k, stride, pad, pad_mode, dtype, transposed=False, output_padding=0, act=ACT_NONE,
+              out_f32=False):
+    """x_shape = (N, Cin, H, W) logical; k / stride / pad = int or (h, w) pair."""
     n, cin, h, w = x_shape
-    kh, kw = (k, k) if isinstance(k, int) else k
-    ho = out_size(h, kh, stride, pad, transposed, output_padding)
-    wo = out_size(w, kw, stride, pad, transposed, output_padding)
-    return ConvDesc(n, h, w, cin, ho, wo, cout, kh, kw, stride, pad, pad_mode, int(transposed), _TORCH2DT[dtype], act)
+    (kh, kw), (sh, sw), (ph, pw) = _pair(k), _pair(stride), _pair(pad)
+    ho = out_size(h, kh, sh, ph, transposed, output_padding)
+    wo = out_size(w, kw, sw, pw, transposed, output_padding)
+    return ConvDesc(n, h, w, cin, ho, wo, cout, kh, kw, sh, sw, ph, pw, pad_mode, int(transposed), _TORCH2DT[dtype],
+                    act, int(out_f32))
 
 
 def is_nhwc(t):
@@ -74,7 +80,8 @@ def conv2d_fwd(desc, x, wpacked, bias=None, want_stats=False, out=None):
         raise ValueError(f"conv2d_fwd: x shape {tuple(x.shape)} does not match the descriptor")
     if not x.is_cuda:
         raise ValueError("conv2d_fwd: GPU tensors only (no CPU fallback)")
-    y = out if out is not None else empty_nhwc(desc.N, desc.Cout, desc.Hout, desc.Wout, x.dtype, x.device)
+    odt = torch.float32 if desc.out_f32 else x.dtype
+    y = out if out is not None else empty_nhwc(desc.N, desc.Cout, desc.Hout, desc.Wout, odt, x.device)
     stats = None
     if want_stats:
         stats = torch.empty((stats_rows(desc), 2, desc.Cout), dtype=torch.float32, device=x.device)

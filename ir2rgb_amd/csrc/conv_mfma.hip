@@ -43,12 +43,13 @@ struct ConvGeom {
     int N, Hin, Win, Cin;
     int Hsub, Wsub;           // sub-grid of output positions computed by this launch
     int Hout, Wout, Cout;
-    int s_in;                 // input coordinate  = sub * s_in  + d{y,x}[tap]
+    int s_in_y, s_in_x;       // input coordinate  = sub * s_in  + tap offset
     int s_out, off_y, off_x;  // output coordinate = sub * s_out + off
     int ntaps, pad_mode;      // pad_mode 0: zeros outside, 1: reflect (no edge repeat)
     int kchunks;              // Cin / 64
     int act;                  // 0: none, 1: LeakyReLU(0.2) after bias
     int stats_row0;           // first row of stats_partial written by this launch
+    int out_f32;              // 1: Y is fp32 NHWC (head convolutions), 0: half
     // taps form an nty x ntx grid: tap (ty,tx) reads input offset (dy0 + ty*dys, dx0 + tx*dxs).
     // Pure scalar arithmetic: no table load sits between the LDS-DMA issues of the K loop.
     int ntx, dy0, dys, dx0, dxs;
@@ -153,8 +154,8 @@ conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W
         unsigned sy = rem / (unsigned)g.Wsub;
         // rows past the last pixel: zero padding -> parked outside the image (read the zero page);
         // reflection -> pixel 0 (harmless, never stored)
-        psy[i] = v ? (int)sy * g.s_in : (g.pad_mode ? 0 : -(1 << 20));
-        psx[i] = (int)(rem - sy * g.Wsub) * g.s_in;
+        psy[i] = v ? (int)sy * g.s_in_y : (g.pad_mode ? 0 : -(1 << 20));
+        psx[i] = (int)(rem - sy * g.Wsub) * g.s_in_x;
         pbase[i] = n * (unsigned)(g.Hin * g.Win);
     }
     const uint16_t *zsrc = reinterpret_cast<const uint16_t *>(g_zero_page) + slot * 8;
@@ -318,9 +319,18 @@ conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W
                 if (g.act == 1) v[r] = v[r] > 0.f ? v[r] : 0.2f * v[r];
                 if (oval[ni]) { s1[r] += v[r]; s2[r] += v[r] * v[r]; }
             }
-            if (oval[ni]) {
+            if (oval[ni] && g.out_f32) {
+                float *dst = reinterpret_cast<float *>(Y) + opix[ni] * g.Cout + co;
+                if (co + 3 < g.Cout && (g.Cout & 3) == 0) {
+                    *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < g.Cout) dst[r] = v[r];
+                }
+            } else if (oval[ni]) {
                 uint16_t *dst = Y + opix[ni] * g.Cout + co;
-                if (co + 3 < g.Cout) {
+                if (co + 3 < g.Cout && (g.Cout & 3) == 0) {
                     uint2 pk;
                     pk.x = (uint32_t)H::cvt(v[0]) | ((uint32_t)H::cvt(v[1]) << 16);
                     pk.y = (uint32_t)H::cvt(v[2]) | ((uint32_t)H::cvt(v[3]) << 16);
@@ -414,27 +424,28 @@ static int tile_pixels(long P, int Cout) {
 // Builds the launch plan(s) for one convolution; returns the number of classes or < 0.
 static int make_plan(const ir2rgb_conv_desc *d, ClassPlan plans[4]) {
     if (!d || d->N < 1 || d->Cin < 64 || (d->Cin % 64) || d->Cout < 1 || d->kh < 1 || d->kw < 1 ||
-        d->kh * d->kw > IR2RGB_MAX_TAPS || d->stride < 1 || d->pad < 0)
+        d->kh * d->kw > IR2RGB_MAX_TAPS || d->stride_h < 1 || d->stride_w < 1 || d->pad_h < 0 || d->pad_w < 0)
         return IR2RGB_EINVAL;
     if (d->dtype != IR2RGB_BF16 && d->dtype != IR2RGB_F16) return IR2RGB_ENOSUP;
     int ncls = 0;
     long woff = 0;
     int row0 = 0;
     if (!d->transposed) {
-        int Ho = (d->Hin + 2 * d->pad - d->kh) / d->stride + 1, Wo = (d->Win + 2 * d->pad - d->kw) / d->stride + 1;
+        int Ho = (d->Hin + 2 * d->pad_h - d->kh) / d->stride_h + 1, Wo = (d->Win + 2 * d->pad_w - d->kw) / d->stride_w + 1;
         if (Ho != d->Hout || Wo != d->Wout || Ho < 1 || Wo < 1) return IR2RGB_EINVAL;
-        if (d->pad_mode == 1 && (d->pad >= d->Hin || d->pad >= d->Win)) return IR2RGB_EINVAL;
+        if (d->pad_mode == 1 && (d->pad_h >= d->Hin || d->pad_w >= d->Win)) return IR2RGB_EINVAL;
         ClassPlan &c = plans[0];
         ConvGeom &g = c.geom;
         g = ConvGeom{};
         g.N = d->N; g.Hin = d->Hin; g.Win = d->Win; g.Cin = d->Cin;
         g.Hsub = Ho; g.Wsub = Wo; g.Hout = Ho; g.Wout = Wo; g.Cout = d->Cout;
-        g.s_in = d->stride; g.s_out = 1; g.off_y = g.off_x = 0;
+        g.s_in_y = d->stride_h; g.s_in_x = d->stride_w; g.s_out = 1; g.off_y = g.off_x = 0;
         g.ntaps = d->kh * d->kw; g.pad_mode = d->pad_mode; g.kchunks = d->Cin / 64; g.act = d->act;
+        g.out_f32 = d->out_f32;
         c.pack = PackGeom{};
         c.pack.Cout = d->Cout; c.pack.Cin = d->Cin; c.pack.kh = d->kh; c.pack.kw = d->kw; c.pack.transposed = 0;
         c.pack.ntaps = g.ntaps;
-        g.ntx = d->kw; g.dy0 = -d->pad; g.dys = 1; g.dx0 = -d->pad; g.dxs = 1;
+        g.ntx = d->kw; g.dy0 = -d->pad_h; g.dys = 1; g.dx0 = -d->pad_w; g.dxs = 1;
         for (int ky = 0, t = 0; ky < d->kh; ++ky)
             for (int kx = 0; kx < d->kw; ++kx, ++t) {
                 c.pack.ky[t] = (signed char)ky; c.pack.kx[t] = (signed char)kx;
@@ -444,9 +455,9 @@ static int make_plan(const ir2rgb_conv_desc *d, ClassPlan plans[4]) {
     } else {
         // stride-2 transposed convolution as 4 sub-pixel (output parity) classes:
         //   oy = 2*iy - pad + ky  ->  for oy = 2*sy + a: ky = (a + pad) mod 2 (+2j), iy = sy + (a + pad - ky)/2
-        if (d->stride != 2 || d->pad_mode != 0) return IR2RGB_ENOSUP;
+        if (d->stride_h != 2 || d->stride_w != 2 || d->pad_mode != 0) return IR2RGB_ENOSUP;
         if ((d->Hout & 1) || (d->Wout & 1) || d->Hout / 2 < 1) return IR2RGB_EINVAL;
-        int Hfull = (d->Hin - 1) * 2 - 2 * d->pad + d->kh, Wfull = (d->Win - 1) * 2 - 2 * d->pad + d->kw;
+        int Hfull = (d->Hin - 1) * 2 - 2 * d->pad_h + d->kh, Wfull = (d->Win - 1) * 2 - 2 * d->pad_w + d->kw;
         if (d->Hout < Hfull || d->Hout > Hfull + 1 || d->Wout < Wfull || d->Wout > Wfull + 1) return IR2RGB_EINVAL;
         for (int a = 0; a < 2; ++a)
             for (int b = 0; b < 2; ++b) {
@@ -455,12 +466,12 @@ static int make_plan(const ir2rgb_conv_desc *d, ClassPlan plans[4]) {
                 g = ConvGeom{};
                 g.N = d->N; g.Hin = d->Hin; g.Win = d->Win; g.Cin = d->Cin;
                 g.Hsub = d->Hout / 2; g.Wsub = d->Wout / 2; g.Hout = d->Hout; g.Wout = d->Wout; g.Cout = d->Cout;
-                g.s_in = 1; g.s_out = 2; g.off_y = a; g.off_x = b;
-                g.pad_mode = 0; g.kchunks = d->Cin / 64; g.act = d->act;
+                g.s_in_y = g.s_in_x = 1; g.s_out = 2; g.off_y = a; g.off_x = b;
+                g.pad_mode = 0; g.kchunks = d->Cin / 64; g.act = d->act; g.out_f32 = d->out_f32;
                 c.pack = PackGeom{};
                 c.pack.Cout = d->Cout; c.pack.Cin = d->Cin; c.pack.kh = d->kh; c.pack.kw = d->kw; c.pack.transposed = 1;
                 int t = 0, ntx = 0;
-                const int ky0 = (a + d->pad) & 1, kx0 = (b + d->pad) & 1;
+                const int ky0 = (a + d->pad_h) & 1, kx0 = (b + d->pad_w) & 1;
                 for (int ky = ky0; ky < d->kh; ky += 2) {
                     ntx = 0;
                     for (int kx = kx0; kx < d->kw; kx += 2, ++t, ++ntx) {
@@ -469,7 +480,7 @@ static int make_plan(const ir2rgb_conv_desc *d, ClassPlan plans[4]) {
                 }
                 if (t == 0) return IR2RGB_ENOSUP;
                 // iy = sy + (a + pad - ky)/2 with ky = ky0 + 2*ty  (numerator even by construction)
-                g.ntx = ntx; g.dy0 = (a + d->pad - ky0) / 2; g.dys = -1; g.dx0 = (b + d->pad - kx0) / 2; g.dxs = -1;
+                g.ntx = ntx; g.dy0 = (a + d->pad_h - ky0) / 2; g.dys = -1; g.dx0 = (b + d->pad_w - kx0) / 2; g.dxs = -1;
                 g.ntaps = t; c.pack.ntaps = t;
                 c.w_offset = woff;
                 woff += (long)d->Cout * d->Cin * t;
@@ -546,6 +557,9 @@ static void launch_conv(const ClassPlan &c, const uint16_t *x, const uint16_t *w
     const int nty = g.ntaps / g.ntx;
     if (nty == 3 && g.ntx == 3)      launch_conv_taps<DT, 3, 3>(c, tp, grid, x, wp, bias, y, stats, s);
     else if (nty == 4 && g.ntx == 4) launch_conv_taps<DT, 4, 4>(c, tp, grid, x, wp, bias, y, stats, s);
+    else if (nty == 7 && g.ntx == 1) launch_conv_taps<DT, 7, 1>(c, tp, grid, x, wp, bias, y, stats, s);
+    else if (nty == 1 && g.ntx == 7) launch_conv_taps<DT, 1, 7>(c, tp, grid, x, wp, bias, y, stats, s);
+    else if (nty == 4 && g.ntx == 1) launch_conv_taps<DT, 4, 1>(c, tp, grid, x, wp, bias, y, stats, s);
     else                             launch_conv_taps<DT, 0, 0>(c, tp, grid, x, wp, bias, y, stats, s);
 }
 

@@ -1,0 +1,243 @@
+// pointwise.hip -- HBM-bound companions of the MFMA convolution (gfx950):
+//   * bn_finalize / bn_apply : training-mode BatchNorm2d + ReLU/LeakyReLU (+ residual adds),
+//     the norm_layer(...) + activation modules of reference models/networks.py:141-171,
+//     :253-271, :556-586, :678-699 (nn.BatchNorm2d semantics incl. running statistics);
+//   * layout converters between the reference's NCHW fp32 tensors and NHWC half;
+//   * xexpand: x-direction im2col for the small-Cin first layers (7x7 on 9/6 channels, 4x4 on
+//     6/13 channels) so they run on the same MFMA kernel as a k x 1 convolution over 64 channels.
+// All kernels move 16 bytes per lane on the NHWC side.
+#include "common.h"
+
+static __device__ __forceinline__ float h2f(uint16_t h, int dt) {
+    if (dt == IR2RGB_BF16) return __uint_as_float(((uint32_t)h) << 16);
+    _Float16 v = __builtin_bit_cast(_Float16, h);
+    return (float)v;
+}
+static __device__ __forceinline__ uint16_t f2h(float f, int dt) {
+    if (dt == IR2RGB_BF16) { __bf16 h = (__bf16)f; return __builtin_bit_cast(uint16_t, h); }
+    _Float16 h = (_Float16)f;
+    return __builtin_bit_cast(uint16_t, h);
+}
+
+// ----------------------------------------------------------------------------------------
+// BatchNorm statistics: reduce the per-tile partials written by the conv epilogue.
+// One lane per channel (coalesced across channels); sums in double: var = E[y^2] - E[y]^2.
+// ----------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+bn_finalize_kernel(const float *__restrict__ partial, int rows, int C, double count, const float *__restrict__ gamma,
+                   const float *__restrict__ beta, float *__restrict__ running_mean, float *__restrict__ running_var,
+                   float momentum, float eps, float *__restrict__ scale, float *__restrict__ shift,
+                   float *__restrict__ mean_out, float *__restrict__ invstd_out) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < rows; ++r) {
+        s1 += (double)partial[((long)r * 2 + 0) * C + c];
+        s2 += (double)partial[((long)r * 2 + 1) * C + c];
+    }
+    double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    float sc = g * invstd;
+    scale[c] = sc;
+    shift[c] = b - (float)mean * sc;
+    if (mean_out) mean_out[c] = (float)mean;
+    if (invstd_out) invstd_out[c] = invstd;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var) {
+        double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+// y = act(x * scale[c] + shift[c]) + r1 + r2   (NHWC half, 8 channels per lane)
+template <int DT>
+__global__ void __launch_bounds__(256)
+bn_apply_kernel(const uint4 *__restrict__ x, const float *__restrict__ scale, const float *__restrict__ shift,
+                const uint4 *__restrict__ r1, const uint4 *__restrict__ r2, uint4 *__restrict__ y, long total8,
+                int C8, int act) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total8; i += (long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % C8) * 8;
+        uint4 v = x[i];
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+        if (r1) { uint4 t = r1[i]; a[0] = t.x; a[1] = t.y; a[2] = t.z; a[3] = t.w; }
+        if (r2) { uint4 t = r2[i]; b[0] = t.x; b[1] = t.y; b[2] = t.z; b[3] = t.w; }
+        const float4 sc0 = *reinterpret_cast<const float4 *>(scale + c0), sc1 = *reinterpret_cast<const float4 *>(scale + c0 + 4);
+        const float4 sh0 = *reinterpret_cast<const float4 *>(shift + c0), sh1 = *reinterpret_cast<const float4 *>(shift + c0 + 4);
+        const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
+        const float sh[8] = {sh0.x, sh0.y, sh0.z, sh0.w, sh1.x, sh1.y, sh1.z, sh1.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float f[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float t = h2f((uint16_t)(w[j] >> (16 * h)), DT) * sc[2 * j + h] + sh[2 * j + h];
+                if (act == 1) t = t > 0.f ? t : 0.f;
+                else if (act == 2) t = t > 0.f ? t : 0.2f * t;
+                if (r1) t += h2f((uint16_t)(a[j] >> (16 * h)), DT);
+                if (r2) t += h2f((uint16_t)(b[j] >> (16 * h)), DT);
+                f[h] = t;
+            }
+            o[j] = (uint32_t)f2h(f[0], DT) | ((uint32_t)f2h(f[1], DT) << 16);
+        }
+        y[i] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// layout converters (LDS-tiled transposes: coalesced on both sides)
+//   NCHW fp32 [N][C][HW]  <->  NHWC half [N][HW][C]
+// tile = 64 pixels x 64 channels per workgroup of 256 threads.
+// ----------------------------------------------------------------------------------------
+template <int DT>
+__global__ void __launch_bounds__(256)
+nchw_to_nhwc_kernel(const float *__restrict__ in, uint16_t *__restrict__ out, int C, long HW) {
+    __shared__ float tile[64][65];
+    const long p0 = (long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64, n = blockIdx.z;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int j = ty; j < 64; j += 4) {
+        int c = c0 + j; long p = p0 + tx;
+        tile[j][tx] = (c < C && p < HW) ? in[((long)n * C + c) * HW + p] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 64; j += 4) {
+        long p = p0 + j; int c = c0 + tx;
+        if (p < HW && c < C) out[((long)n * HW + p) * C + c] = f2h(tile[tx][j], DT);
+    }
+}
+
+template <int DT>
+__global__ void __launch_bounds__(256)
+nhwc_to_nchw_kernel(const uint16_t *__restrict__ in, float *__restrict__ out, int C, long HW) {
+    __shared__ float tile[64][65];
+    const long p0 = (long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64, n = blockIdx.z;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int j = ty; j < 64; j += 4) {
+        long p = p0 + j; int c = c0 + tx;
+        tile[j][tx] = (p < HW && c < C) ? h2f(in[((long)n * HW + p) * C + c], DT) : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 64; j += 4) {
+        int c = c0 + j; long p = p0 + tx;
+        if (c < C && p < HW) out[((long)n * C + c) * HW + p] = tile[tx][j];
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// xexpand: out[n][y][ox][ci*KW + kx] = in[n][ci][y][pad(ox*sx + kx - px)]   (channels >= Cin*KW: 0)
+//   in NCHW fp32 (Cin*KW <= 64), out NHWC half with 64 channels.  One lane per 8 output
+//   channels (16-byte stores); the NCHW reads of a wave walk x, so they coalesce per (ci,kx).
+// ----------------------------------------------------------------------------------------
+template <int DT>
+__global__ void __launch_bounds__(256)
+xexpand_kernel(const float *__restrict__ in, uint4 *__restrict__ out, int Cin, int H, int W, int Wout, int KW,
+               int sx, int px, int pad_mode, long total) {
+    // total = N*H*Wout*8 (8 lanes per output pixel)
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int j0 = (int)(i & 7) * 8;
+        long pix = i >> 3;
+        const int ox = (int)(pix % Wout); pix /= Wout;
+        const int y = (int)(pix % H);
+        const int n = (int)(pix / H);
+        uint32_t o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint16_t hv[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int j = j0 + 2 * q + h;
+                float v = 0.f;
+                if (j < Cin * KW) {
+                    const int ci = j / KW, kx = j - ci * KW;
+                    int ix = ox * sx + kx - px;
+                    bool ok = true;
+                    if (pad_mode) { ix = ix < 0 ? -ix : ix; ix = ix >= W ? 2 * W - 2 - ix : ix; }
+                    else ok = ix >= 0 && ix < W;
+                    if (ok) v = in[(((long)n * Cin + ci) * H + y) * W + ix];
+                }
+                hv[h] = f2h(v, DT);
+            }
+            o[q] = (uint32_t)hv[0] | ((uint32_t)hv[1] << 16);
+        }
+        out[i] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// C ABI
+// ----------------------------------------------------------------------------------------
+extern "C" int ir2rgb_bn_finalize(const float *stats_partial, int rows, int C, long count, const float *gamma,
+                                  const float *beta, float *running_mean, float *running_var, float momentum,
+                                  float eps, float *scale, float *shift, float *mean_out, float *invstd_out,
+                                  void *stream) {
+    if (rows < 1 || C < 1 || count < 1 || !stats_partial || !scale || !shift) return IR2RGB_EINVAL;
+    bn_finalize_kernel<<<cdiv(C, 256), 256, 0, as_stream(stream)>>>(stats_partial, rows, C, (double)count, gamma, beta,
+                                                                    running_mean, running_var, momentum, eps, scale,
+                                                                    shift, mean_out, invstd_out);
+    return ir2rgb_launch_status();
+}
+
+extern "C" int ir2rgb_bn_apply(const void *x, const float *scale, const float *shift, const void *res1,
+                               const void *res2, void *y, long npix, int C, int act, int dtype, void *stream) {
+    if (npix < 0 || C < 8 || (C % 8) || act < 0 || act > 2) return IR2RGB_EINVAL;
+    if (dtype != IR2RGB_BF16 && dtype != IR2RGB_F16) return IR2RGB_ENOSUP;
+    if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)res1 | (uintptr_t)res2 | (uintptr_t)scale | (uintptr_t)shift) & 15))
+        return IR2RGB_EALIGN;
+    long total8 = npix * (C / 8);
+    if (total8 == 0) return IR2RGB_OK;
+    int grid = stream_grid(total8, 256);
+    if (dtype == IR2RGB_BF16)
+        bn_apply_kernel<IR2RGB_BF16><<<grid, 256, 0, as_stream(stream)>>>((const uint4 *)x, scale, shift, (const uint4 *)res1,
+                                                                          (const uint4 *)res2, (uint4 *)y, total8, C / 8, act);
+    else
+        bn_apply_kernel<IR2RGB_F16><<<grid, 256, 0, as_stream(stream)>>>((const uint4 *)x, scale, shift, (const uint4 *)res1,
+                                                                         (const uint4 *)res2, (uint4 *)y, total8, C / 8, act);
+    return ir2rgb_launch_status();
+}
+
+extern "C" int ir2rgb_nchw_f32_to_nhwc_half(const float *in, void *out, int N, int C, int H, int W, int dtype,
+                                            void *stream) {
+    if (N < 0 || C < 1 || H < 1 || W < 1) return IR2RGB_EINVAL;
+    if (dtype != IR2RGB_BF16 && dtype != IR2RGB_F16) return IR2RGB_ENOSUP;
+    if (N == 0) return IR2RGB_OK;
+    long HW = (long)H * W;
+    dim3 grid((unsigned)cdiv(HW, 64), (unsigned)cdiv(C, 64), (unsigned)N);
+    if (dtype == IR2RGB_BF16) nchw_to_nhwc_kernel<IR2RGB_BF16><<<grid, 256, 0, as_stream(stream)>>>(in, (uint16_t *)out, C, HW);
+    else nchw_to_nhwc_kernel<IR2RGB_F16><<<grid, 256, 0, as_stream(stream)>>>(in, (uint16_t *)out, C, HW);
+    return ir2rgb_launch_status();
+}
+
+extern "C" int ir2rgb_nhwc_half_to_nchw_f32(const void *in, float *out, int N, int C, int H, int W, int dtype,
+                                            void *stream) {
+    if (N < 0 || C < 1 || H < 1 || W < 1) return IR2RGB_EINVAL;
+    if (dtype != IR2RGB_BF16 && dtype != IR2RGB_F16) return IR2RGB_ENOSUP;
+    if (N == 0) return IR2RGB_OK;
+    long HW = (long)H * W;
+    dim3 grid((unsigned)cdiv(HW, 64), (unsigned)cdiv(C, 64), (unsigned)N);
+    if (dtype == IR2RGB_BF16) nhwc_to_nchw_kernel<IR2RGB_BF16><<<grid, 256, 0, as_stream(stream)>>>((const uint16_t *)in, out, C, HW);
+    else nhwc_to_nchw_kernel<IR2RGB_F16><<<grid, 256, 0, as_stream(stream)>>>((const uint16_t *)in, out, C, HW);
+    return ir2rgb_launch_status();
+}
+
+extern "C" int ir2rgb_xexpand(const float *in, void *out, int N, int Cin, int H, int W, int Wout, int KW, int stride_w,
+                              int pad_w, int pad_mode, int dtype, void *stream) {
+    if (N < 0 || Cin < 1 || H < 1 || W < 1 || Wout < 1 || KW < 1 || Cin * KW > 64 || stride_w < 1 || pad_w < 0)
+        return IR2RGB_EINVAL;
+    if (pad_mode == 1 && pad_w >= W) return IR2RGB_EINVAL;
+    if ((Wout - 1) * stride_w + KW - pad_w > W + pad_w) return IR2RGB_EINVAL;  // would read past the padded row
+    if (dtype != IR2RGB_BF16 && dtype != IR2RGB_F16) return IR2RGB_ENOSUP;
+    long total = (long)N * H * Wout * 8;
+    if (total == 0) return IR2RGB_OK;
+    int grid = stream_grid(total, 256);
+    if (dtype == IR2RGB_BF16)
+        xexpand_kernel<IR2RGB_BF16><<<grid, 256, 0, as_stream(stream)>>>(in, (uint4 *)out, Cin, H, W, Wout, KW, stride_w, pad_w, pad_mode, total);
+    else
+        xexpand_kernel<IR2RGB_F16><<<grid, 256, 0, as_stream(stream)>>>(in, (uint4 *)out, Cin, H, W, Wout, KW, stride_w, pad_w, pad_mode, total);
+    return ir2rgb_launch_status();
+}

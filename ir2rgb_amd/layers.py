@@ -1,0 +1,251 @@
+"""Fused layer primitives on NHWC half tensors, each a thin sequence of libir2rgb_hip.so calls.
+
+A "stage" is what the reference writes as ``[pad, conv, norm, activation]`` module runs
+(models/networks.py:141-171, :253-271, :556-580, :678-699):
+
+    conv (MFMA implicit GEMM, bias + per-tile BatchNorm partial sums fused in the epilogue)
+      -> bn_finalize (batch statistics, running-stat update)
+      -> bn_apply    (scale/shift + ReLU / LeakyReLU + up to two residual adds)
+
+Parameters stay in the fp32 ``nn.Conv2d`` / ``nn.BatchNorm2d`` containers the state_dict
+exposes; the half-precision packed copy the MFMA kernel streams is cached per module and
+refreshed whenever the fp32 weight's version counter moves (optimizer step, load_state_dict).
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from . import conv as C
+
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+_DT = {torch.bfloat16: 1, torch.float16: 2}
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _require_gpu(t, what):
+    if not t.is_cuda:
+        raise ValueError(f"{what}: ir2rgb_amd runs on an AMD GPU only (no CPU fallback)")
+
+
+# ---------------------------------------------------------------------------------------------
+# packed-weight cache
+# ---------------------------------------------------------------------------------------------
+def packed_weight(mod, desc, weight=None, tag="w"):
+    """Packed half copy of ``mod.weight`` (or of ``weight``, a rearranged view of it) for ``desc``."""
+    src = mod.weight
+    key = (tag, desc.dtype, src._version, src.data_ptr(), desc.Cin, desc.Cout, desc.kh, desc.kw, desc.transposed)
+    cache = mod.__dict__.setdefault("_ir2rgb_packed", {})
+    hit = cache.get(tag)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    with torch.no_grad():
+        w = (src if weight is None else weight(src)).detach().float().contiguous()
+        packed = C.pack_weight(desc, w)
+    cache[tag] = (key, packed)
+    return packed
+
+
+# ---------------------------------------------------------------------------------------------
+# BatchNorm pieces
+# ---------------------------------------------------------------------------------------------
+def bn_finalize(stats, count, bn, training=True):
+    """-> (scale, shift, mean, invstd) fp32 [C].  Updates bn.running_* like nn.BatchNorm2d."""
+    rows, _, ch = stats.shape
+    dev = stats.device
+    scale = torch.empty(ch, dtype=torch.float32, device=dev)
+    shift = torch.empty_like(scale)
+    mean = torch.empty_like(scale)
+    invstd = torch.empty_like(scale)
+    track = training and bn.track_running_stats and bn.running_mean is not None
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    with torch.cuda.device_of(stats):
+        rc = _lib.lib().ir2rgb_bn_finalize(_p(stats), rows, ch, int(count), _p(bn.weight), _p(bn.bias),
+                                           _p(bn.running_mean) if track else _p(None),
+                                           _p(bn.running_var) if track else _p(None), float(momentum), float(bn.eps),
+                                           _p(scale), _p(shift), _p(mean), _p(invstd), _lib.current_stream(stats))
+    _lib.check(rc, "bn_finalize")
+    if track and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return scale, shift, mean, invstd
+
+
+def bn_apply(x, scale, shift, act=ACT_NONE, res1=None, res2=None, out=None):
+    n, ch, h, w = x.shape
+    y = out if out is not None else torch.empty_like(x, memory_format=torch.channels_last)
+    with torch.cuda.device_of(x):
+        rc = _lib.lib().ir2rgb_bn_apply(_p(x), _p(scale), _p(shift), _p(res1), _p(res2), _p(y), n * h * w, ch, act,
+                                        _DT[x.dtype], _lib.current_stream(x))
+    _lib.check(rc, "bn_apply")
+    return y
+
+
+# ---------------------------------------------------------------------------------------------
+# layout converters
+# ---------------------------------------------------------------------------------------------
+def to_nhwc_half(x, dtype):
+    """NCHW fp32 -> logical NCHW / channels_last half (zero copy if already in that form)."""
+    if x.dtype == dtype and C.is_nhwc(x):
+        return x
+    _require_gpu(x, "to_nhwc_half")
+    x = x.float().contiguous()
+    n, ch, h, w = x.shape
+    y = C.empty_nhwc(n, ch, h, w, dtype, x.device)
+    with torch.cuda.device_of(x):
+        rc = _lib.lib().ir2rgb_nchw_f32_to_nhwc_half(_p(x), _p(y), n, ch, h, w, _DT[dtype], _lib.current_stream(x))
+    _lib.check(rc, "nchw_f32_to_nhwc_half")
+    return y
+
+
+def to_nchw_f32(x):
+    """channels_last half -> contiguous NCHW fp32."""
+    if x.dtype == torch.float32 and x.is_contiguous():
+        return x
+    if not C.is_nhwc(x) or x.dtype not in _DT:
+        return x.float().contiguous()
+    n, ch, h, w = x.shape
+    y = torch.empty((n, ch, h, w), dtype=torch.float32, device=x.device)
+    with torch.cuda.device_of(x):
+        rc = _lib.lib().ir2rgb_nhwc_half_to_nchw_f32(_p(x), _p(y), n, ch, h, w, _DT[x.dtype], _lib.current_stream(x))
+    _lib.check(rc, "nhwc_half_to_nchw_f32")
+    return y
+
+
+def xexpand(x, kw, stride_w, pad_w, pad_mode, dtype):
+    """NCHW fp32 [N,Cin,H,W] -> channels_last half [N,64,H,Wout] with channel ci*kw+kx = x[ci][.., ox*s+kx-p]."""
+    _require_gpu(x, "xexpand")
+    x = x.float().contiguous()
+    n, cin, h, w = x.shape
+    wout = (w + 2 * pad_w - kw) // stride_w + 1
+    y = C.empty_nhwc(n, 64, h, wout, dtype, x.device)
+    with torch.cuda.device_of(x):
+        rc = _lib.lib().ir2rgb_xexpand(_p(x), _p(y), n, cin, h, w, wout, kw, stride_w, pad_w, pad_mode, _DT[dtype],
+                                       _lib.current_stream(x))
+    _lib.check(rc, "xexpand")
+    return y
+
+
+def _xexpanded_weight(kw):
+    """[Cout,Cin,kh,kw] -> [Cout,64,kh,1] with input channel ci*kw+kx (zero padded to 64)."""
+    def f(w):
+        co, ci, kh, kw_ = w.shape
+        assert kw_ == kw and ci * kw <= 64
+        v = w.permute(0, 2, 1, 3).reshape(co, kh, ci * kw)       # [co][ky][ci*kw+kx]
+        v = torch.nn.functional.pad(v, (0, 64 - ci * kw))        # [co][ky][64]
+        return v.permute(0, 2, 1).unsqueeze(-1)                  # [co][64][ky][1]
+    return f
+
+
+def _ysplit_weight(w):
+    """[Cout,Cin,kh,kw] -> [pad24(Cout*kh),Cin,1,kw]: output channel co*kh+ky holds row ky of the kernel."""
+    co, ci, kh, kw = w.shape
+    v = w.permute(0, 2, 1, 3).reshape(co * kh, ci, 1, kw)
+    pad = (-v.shape[0]) % 8
+    if pad:
+        v = torch.cat([v, v.new_zeros(pad, ci, 1, kw)], 0)
+    return v
+
+
+# ---------------------------------------------------------------------------------------------
+# stages
+# ---------------------------------------------------------------------------------------------
+def conv_stage(x, conv, bn, act, pad_mode, *, stride=None, pad=None, transposed=False, output_padding=0,
+               res1=None, res2=None, fused_leaky=False, training=True):
+    """x (channels_last half) -> act(bn(conv(x))) [+ res1 + res2].  ``bn`` may be None."""
+    stride = conv.stride if stride is None else stride
+    pad = conv.padding if pad is None else pad
+    desc = C.make_desc(tuple(x.shape), conv.out_channels, conv.kernel_size, stride, pad, pad_mode, x.dtype, transposed,
+                       output_padding, act=1 if fused_leaky else 0)
+    wp = packed_weight(conv, desc)
+    y, stats = C.conv2d_fwd(desc, x, wp, conv.bias, want_stats=bn is not None)
+    if bn is None:
+        return y
+    scale, shift, _, _ = bn_finalize(stats, desc.N * desc.Hout * desc.Wout, bn, training)
+    return bn_apply(y, scale, shift, act, res1, res2, out=y)
+
+
+def first_stage(x_nchw, conv, bn, act, pad_mode, dtype, *, fused_leaky=False, training=True):
+    """Small-Cin first layer on an NCHW fp32 image: x-im2col + (kh x 1) MFMA convolution.
+
+    ReflectionPad2d(3)+Conv7x7 (networks.py:141,:150,:253-255) or Conv4x4 s2 p2 (:680)."""
+    kh, kw = conv.kernel_size
+    sh, sw = conv.stride
+    ph, pw = (3, 3) if pad_mode == C.PAD_REFLECT else conv.padding
+    if conv.in_channels * kw > 64:
+        raise NotImplementedError(f"first layer with {conv.in_channels} input channels x kernel width {kw} > 64")
+    xe = xexpand(x_nchw, kw, sw, pw, pad_mode, dtype)
+    desc = C.make_desc(tuple(xe.shape), conv.out_channels, (kh, 1), (sh, 1), (ph, 0), pad_mode, dtype,
+                       act=1 if fused_leaky else 0)
+    wp = packed_weight(conv, desc, _xexpanded_weight(kw), tag="xexp")
+    y, stats = C.conv2d_fwd(desc, xe, wp, conv.bias, want_stats=bn is not None)
+    if bn is None:
+        return y
+    scale, shift, _, _ = bn_finalize(stats, desc.N * desc.Hout * desc.Wout, bn, training)
+    return bn_apply(y, scale, shift, act, out=y)
+
+
+def head_stage(feat, convs, acts, mul=1.0):
+    """ReflectionPad2d(3)+Conv7x7 heads with tiny Cout on a channels_last half feature map.
+
+    ``convs`` is a list of nn.Conv2d reading the SAME feature map (e.g. flow and weight heads,
+    networks.py:170-171); they are evaluated as one separable convolution: a 1x7 MFMA pass
+    producing Cout*7 fp32 row responses, then a 7-tap vertical gather with bias and the output
+    non-linearity.  ``acts``: per output channel 0 linear*mul, 1 tanh, 2 sigmoid.
+    Returns NCHW fp32 [N, sum Cout, H, W]."""
+    kh, kw = convs[0].kernel_size
+    cout = sum(c.out_channels for c in convs)
+    n, _, h, w = feat.shape
+    desc = C.make_desc(tuple(feat.shape), (cout * kh + 7) // 8 * 8, (1, kw), 1, (0, kw // 2), C.PAD_REFLECT, feat.dtype,
+                       out_f32=True)
+    holder = convs[0]
+    key = ("ysplit", desc.dtype) + tuple((c.weight._version, c.weight.data_ptr()) for c in convs)
+    cache = holder.__dict__.setdefault("_ir2rgb_packed", {})
+    hit = cache.get("ysplit")
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            wcat = torch.cat([c.weight.detach().float() for c in convs], 0)
+            cache["ysplit"] = (key, C.pack_weight(desc, _ysplit_weight(wcat).contiguous()))
+    wp = cache["ysplit"][1]
+    t, _ = C.conv2d_fwd(desc, feat, wp, None, want_stats=False)
+    bias = torch.cat([c.bias.detach().float() for c in convs], 0).contiguous()
+    out = torch.empty((n, cout, h, w), dtype=torch.float32, device=feat.device)
+    packed_acts = 0
+    for i, a in enumerate(acts):
+        packed_acts |= (a & 15) << (4 * i)
+    with torch.cuda.device_of(feat):
+        rc = _lib.lib().ir2rgb_head_finish(_p(t), _p(bias), _p(out), n, h, w, cout, kh, desc.Cout, kh // 2,
+                                           packed_acts, float(mul), _lib.current_stream(feat))
+    _lib.check(rc, "head_finish")
+    return out
+
+
+def warp_blend(raw, prev, flow, weight, want_warp=False):
+    """img_final = raw*w + grid_sample(prev[:, -3:], grid+flow)*(1-w)  (networks.py:207-209)."""
+    for t in (raw, prev, flow, weight):
+        _lib.require_device(t, dtype=torch.float32)
+    n, _, h, w = raw.shape
+    out = torch.empty_like(raw)
+    warp = torch.empty_like(raw) if want_warp else None
+    with torch.cuda.device_of(raw):
+        rc = _lib.lib().ir2rgb_warp_blend_fwd(_p(raw), _p(prev), _p(flow), _p(weight), _p(out), _p(warp), n,
+                                              prev.shape[1], h, w, _lib.current_stream(raw))
+    _lib.check(rc, "warp_blend_fwd")
+    return (out, warp) if want_warp else out
+
+
+_UNIT = {}
+
+
+def bn_apply_add(a, b):
+    """a + b on channels_last half tensors (bn_apply with unit scale / zero shift)."""
+    ch = a.shape[1]
+    key = (ch, a.device)
+    if key not in _UNIT:
+        _UNIT[key] = (torch.ones(ch, dtype=torch.float32, device=a.device),
+                      torch.zeros(ch, dtype=torch.float32, device=a.device))
+    one, zero = _UNIT[key]
+    return bn_apply(a, one, zero, ACT_NONE, res1=b)

@@ -1,0 +1,393 @@
+"""MI355X-native generator / discriminator modules behind the reference's factory API.
+
+Drop-in for the factories of reference models/networks.py:
+
+    build_generator_module(input_nc, output_nc, prev_output_nc, ngf, model_name, n_downsampling,
+                           norm, scale, **opt)                                   (:51-75)
+    build_discriminator_module(input_nc, ndf, n_layers_D, norm, num_D, get_interm_feat)   (:78-82)
+
+Same signatures, same returned-module call signatures / return tuples (:191,:220,:288,:317,
+:656-668), same ``state_dict`` key names and the same construction order of the parameter
+containers -- so the same ``torch.manual_seed`` yields bit-identical initial weights and
+reference checkpoints (``*_net_G0.pth`` ...) load unchanged.  What differs is everything that
+executes: ``forward`` never calls a torch convolution; it drives the hand-written gfx950 kernels
+of libir2rgb_hip.so (MFMA implicit-GEMM convolutions on NHWC half tensors with fp32
+accumulation, fused BatchNorm statistics, fp32 heads / warp / blend).  There is no CPU path:
+CPU tensors raise.
+
+Compute precision: ``module.compute_dtype`` (torch.bfloat16 default, torch.float16 optional) is
+the MFMA operand type of the dense layers; batch statistics, heads, flow, warp and blend are fp32.
+
+Feature maps returned for the next scale (``img_feat``, ``flow_feat``) are logical NCHW tensors
+in channels_last half precision (the kernels' native layout, zero copy); ``.float()`` gives the
+reference's dense fp32 form.
+"""
+import copy
+import functools
+
+import torch
+import torch.nn as nn
+from torch.nn import init
+
+from . import conv as C
+from . import layers as L
+
+__all__ = ["build_generator_module", "build_discriminator_module", "get_grid", "weights_init", "get_norm_layer",
+           "CompositeGeneratorModule", "CompositeLocalGeneratorModule", "MultiScaleDiscriminator", "NLayerDiscriminator",
+           "ResnetBlock"]
+
+
+# ---------------------------------------------------------------------------------------------
+# helpers shared with the reference API surface
+# ---------------------------------------------------------------------------------------------
+def get_grid(batch_size, rows, cols, device="cuda:0", dtype=torch.float32):
+    """[-1,1] x [-1,1] lattice, channel 0 = x, channel 1 = y (reference networks.py:15-28)."""
+    xs = torch.linspace(-1.0, 1.0, cols).view(1, 1, 1, cols).expand(batch_size, 1, rows, cols)
+    ys = torch.linspace(-1.0, 1.0, rows).view(1, 1, rows, 1).expand(batch_size, 1, rows, cols)
+    return torch.cat([xs, ys], 1).to(dtype).to(device)
+
+
+def weights_init(m):
+    """Reference init (networks.py:31-38): conv W ~ N(0, 0.02); BN gamma ~ N(1, 0.02), beta = 0."""
+    if isinstance(m, (nn.Conv2d, nn.Conv3d)):
+        init.normal_(m.weight, 0.0, 0.02)
+    if isinstance(m, nn.BatchNorm2d):
+        init.normal_(m.weight, 1.0, 0.02)
+        init.zeros_(m.bias)
+    if isinstance(m, nn.InstanceNorm2d) and m.weight is not None:
+        init.normal_(m.weight, 1.0, 0.02)
+
+
+def get_norm_layer(norm_type="instance"):
+    if norm_type == "batch":
+        return functools.partial(nn.BatchNorm2d, affine=True)
+    if norm_type == "instance":
+        # The reference's instance branch crashes in weights_init (affine=False leaves weight=None,
+        # networks.py:37-38,:45); the IR->RGB path always runs norm='batch'.
+        raise NotImplementedError("norm='instance' is not runnable in the reference either; use norm='batch'")
+    raise NotImplementedError(f"normalization layer {norm_type} is not found")
+
+
+def _seq(mods):
+    return nn.Sequential(*mods)
+
+
+class ResnetBlock(nn.Module):
+    """x + [pad, conv3x3, norm, ReLU, pad, conv3x3, norm](x)   (reference networks.py:547-586).
+
+    ``conv_block`` indices 1,2,5,6 hold the parameters, as in the reference."""
+
+    def __init__(self, dim, padding_type, norm_layer, activation=None, use_dropout=False):
+        super().__init__()
+        if padding_type != "reflect" or use_dropout:
+            raise NotImplementedError("only padding_type='reflect' without dropout is used by the IR->RGB path")
+        self.conv_block = _seq([nn.ReflectionPad2d(1), nn.Conv2d(dim, dim, kernel_size=3, padding=0), norm_layer(dim),
+                                nn.ReLU(True), nn.ReflectionPad2d(1), nn.Conv2d(dim, dim, kernel_size=3, padding=0),
+                                norm_layer(dim)])
+
+    def run(self, x, extra_residual=None):
+        """NHWC half in/out; ``extra_residual`` is added to the block output (encoder sum)."""
+        cb, tr = self.conv_block, self.training
+        h = L.conv_stage(x, cb[1], cb[2], L.ACT_RELU, C.PAD_REFLECT, pad=1, training=tr)
+        return L.conv_stage(h, cb[5], cb[6], L.ACT_NONE, C.PAD_REFLECT, pad=1, res1=x, res2=extra_residual, training=tr)
+
+    def forward(self, x):
+        dt = getattr(self, "compute_dtype", torch.bfloat16)
+        return self.run(L.to_nhwc_half(x, dt))
+
+
+# ---------------------------------------------------------------------------------------------
+# runners over nn.Sequential parameter containers
+# ---------------------------------------------------------------------------------------------
+def _run_sequence(seq, x, dtype, training, final_residual=None):
+    """Executes a reference-structured nn.Sequential on the HIP kernels.
+
+    Recognised runs: [ReflectionPad2d(3), Conv7x7, BN, ReLU] on an NCHW fp32 image (first layer),
+    [Conv3x3 s2, BN, ReLU], [ConvTranspose3x3 s2, BN, ReLU], ResnetBlock.  ``final_residual`` is
+    added to the output of the last ResnetBlock (fuses the encoder sum of networks.py:192)."""
+    mods = list(seq)
+    i, n = 0, len(mods)
+    last_block = max((j for j, m in enumerate(mods) if isinstance(m, ResnetBlock)), default=-1)
+    while i < n:
+        m = mods[i]
+        if isinstance(m, nn.ReflectionPad2d):
+            conv, bn = mods[i + 1], mods[i + 2]
+            x = L.first_stage(x, conv, bn, L.ACT_RELU, C.PAD_REFLECT, dtype, training=training)
+            i += 4
+        elif isinstance(m, nn.ConvTranspose2d):
+            x = L.conv_stage(x, m, mods[i + 1], L.ACT_RELU, C.PAD_ZERO, transposed=True,
+                             output_padding=m.output_padding[0], training=training)
+            i += 3
+        elif isinstance(m, nn.Conv2d):
+            x = L.conv_stage(x, m, mods[i + 1], L.ACT_RELU, C.PAD_ZERO, training=training)
+            i += 3
+        elif isinstance(m, ResnetBlock):
+            x = m.run(x, final_residual if i == last_block else None)
+            i += 1
+        else:
+            raise RuntimeError(f"unexpected module {type(m).__name__} in generator sequence")
+    if final_residual is not None and last_block < 0:
+        raise RuntimeError("final_residual needs a ResnetBlock in the sequence")
+    return x
+
+
+def _first7(nc_in, nc_out, norm_layer):
+    return [nn.ReflectionPad2d(3), nn.Conv2d(nc_in, nc_out, kernel_size=7, padding=0), norm_layer(nc_out), nn.ReLU(True)]
+
+
+def _down(nc_in, norm_layer):
+    return [nn.Conv2d(nc_in, nc_in * 2, kernel_size=3, stride=2, padding=1), norm_layer(nc_in * 2), nn.ReLU(True)]
+
+
+def _up(nc_in, norm_layer):
+    return [nn.ConvTranspose2d(nc_in, nc_in // 2, kernel_size=3, stride=2, padding=1, output_padding=1),
+            norm_layer(nc_in // 2), nn.ReLU(True)]
+
+
+def _check_ngf(ngf):
+    if ngf % 64:
+        raise NotImplementedError(f"ngf/ndf must be a multiple of 64 for the MFMA kernels (got {ngf})")
+
+
+class _CompositeBase(nn.Module):
+    compute_dtype = torch.bfloat16
+
+    def _heads_and_blend(self, img_feat, flow_feat, img_prev, use_raw_only, flow_mul):
+        img_raw = L.head_stage(img_feat, [self.model_final_img[1]], [1] * self.model_final_img[1].out_channels)
+        flow = weight = None
+        if not self.no_flow:
+            fw = L.head_stage(flow_feat, [self.model_final_flow[1], self.model_final_w[1]], [0, 0, 2], mul=flow_mul)
+            flow, weight = fw[:, 0:2], fw[:, 2:3]
+        if use_raw_only or self.no_flow:
+            img_final = img_raw
+        else:
+            img_final = L.warp_blend(img_raw, img_prev.float().contiguous(), flow.contiguous(), weight.contiguous())
+        return img_final, flow, weight, img_raw
+
+    @staticmethod
+    def _check_inputs(input, img_prev):
+        if not input.is_cuda or not img_prev.is_cuda:
+            raise ValueError("ir2rgb_amd generators run on an AMD GPU only (no CPU fallback)")
+
+
+class CompositeGeneratorModule(_CompositeBase):
+    """Coarse-scale vid2vid generator (reference networks.py:103-220), HIP execution."""
+
+    def __init__(self, input_nc, output_nc, prev_output_nc, ngf, n_downsampling, n_blocks, use_fg_model=False,
+                 no_flow=False, norm_layer=nn.BatchNorm2d, padding_type="reflect"):
+        super().__init__()
+        if use_fg_model:
+            raise NotImplementedError("foreground model (fg=True) is a dead branch for IR->RGB")
+        _check_ngf(ngf)
+        self.use_fg_model, self.no_flow = False, no_flow
+        res = lambda: ResnetBlock(ngf * 2 ** n_downsampling, padding_type, norm_layer)  # noqa: E731
+
+        # construction order == reference order: same RNG stream, same initial weights
+        down_seg = _first7(input_nc, ngf, norm_layer)
+        for i in range(n_downsampling):
+            down_seg += _down(ngf * 2 ** i, norm_layer)
+        down_seg += [res() for _ in range(n_blocks - n_blocks // 2)]
+        down_img = _first7(prev_output_nc, ngf, norm_layer) + copy.deepcopy(down_seg[4:])
+        res_img = [res() for _ in range(n_blocks // 2)]
+        res_flow = copy.deepcopy(res_img) if not no_flow else None
+        up_img = []
+        for i in range(n_downsampling):
+            up_img += _up(ngf * 2 ** (n_downsampling - i), norm_layer)
+        final_img = [nn.ReflectionPad2d(3), nn.Conv2d(ngf, output_nc, kernel_size=7, padding=0), nn.Tanh()]
+        if not no_flow:
+            up_flow = copy.deepcopy(up_img)
+            final_flow = [nn.ReflectionPad2d(3), nn.Conv2d(ngf, 2, kernel_size=7, padding=0)]
+            final_w = [nn.ReflectionPad2d(3), nn.Conv2d(ngf, 1, kernel_size=7, padding=0), nn.Sigmoid()]
+
+        self.model_down_seg = _seq(down_seg)
+        self.model_down_img = _seq(down_img)
+        self.model_res_img = _seq(res_img)
+        self.model_up_img = _seq(up_img)
+        self.model_final_img = _seq(final_img)
+        if not no_flow:
+            self.model_res_flow = _seq(res_flow)
+            self.model_up_flow = _seq(up_flow)
+            self.model_final_flow = _seq(final_flow)
+            self.model_final_w = _seq(final_w)
+
+    def forward(self, input, img_prev, mask, img_feat_coarse, flow_feat_coarse, img_fg_feat_coarse, use_raw_only):
+        self._check_inputs(input, img_prev)
+        dt, tr = self.compute_dtype, self.training
+        seg = _run_sequence(self.model_down_seg, input, dt, tr)
+        downsample = _run_sequence(self.model_down_img, img_prev, dt, tr, final_residual=seg)  # seg + img (:192)
+        img_feat = _run_sequence(self.model_up_img, _run_sequence(self.model_res_img, downsample, dt, tr), dt, tr)
+        flow_feat = None
+        if not self.no_flow:
+            flow_feat = _run_sequence(self.model_up_flow, _run_sequence(self.model_res_flow, downsample, dt, tr), dt, tr)
+        img_final, flow, weight, img_raw = self._heads_and_blend(img_feat, flow_feat, img_prev, use_raw_only, 20.0)
+        return img_final, flow, weight, img_raw, img_feat, flow_feat, None
+
+
+class CompositeLocalGeneratorModule(_CompositeBase):
+    """Finer-scale generator fed with coarse features (reference networks.py:223-317), HIP execution."""
+
+    def __init__(self, input_nc, output_nc, prev_output_nc, ngf, n_downsampling, n_blocks_local, use_fg_model=False,
+                 no_flow=False, norm_layer=nn.BatchNorm2d, padding_type="reflect", scale=1):
+        super().__init__()
+        if use_fg_model:
+            raise NotImplementedError("foreground model (fg=True) is a dead branch for IR->RGB")
+        _check_ngf(ngf)
+        self.use_fg_model, self.no_flow, self.scale = False, no_flow, scale
+        down_seg = _first7(input_nc, ngf, norm_layer) + _down(ngf, norm_layer)
+        down_img = _first7(prev_output_nc, ngf, norm_layer) + _down(ngf, norm_layer)
+        up_img = [ResnetBlock(ngf * 2, padding_type, norm_layer) for _ in range(n_blocks_local)] + _up(ngf * 2, norm_layer)
+        final_img = [nn.ReflectionPad2d(3), nn.Conv2d(ngf, output_nc, kernel_size=7, padding=0), nn.Tanh()]
+        if not no_flow:
+            up_flow = copy.deepcopy(up_img)
+            final_flow = [nn.ReflectionPad2d(3), nn.Conv2d(ngf, 2, kernel_size=7, padding=0)]
+            final_w = [nn.ReflectionPad2d(3), nn.Conv2d(ngf, 1, kernel_size=7, padding=0), nn.Sigmoid()]
+        self.model_down_seg = _seq(down_seg)
+        self.model_down_img = _seq(down_img)
+        self.model_up_img = _seq(up_img)
+        self.model_final_img = _seq(final_img)
+        if not no_flow:
+            self.model_up_flow = _seq(up_flow)
+            self.model_final_flow = _seq(final_flow)
+            self.model_final_w = _seq(final_w)
+
+    def _encode(self, seq, x, dt, tr, res1=None, res2=None):
+        mods = list(seq)
+        h = L.first_stage(x, mods[1], mods[2], L.ACT_RELU, C.PAD_REFLECT, dt, training=tr)
+        desc_conv, bn = mods[4], mods[5]
+        # the stride-2 stage ends the encoder: residual adds (other encoder, coarse features) fuse here
+        desc = C.make_desc(tuple(h.shape), desc_conv.out_channels, 3, 2, 1, C.PAD_ZERO, h.dtype)
+        y, stats = C.conv2d_fwd(desc, h, L.packed_weight(desc_conv, desc), desc_conv.bias, want_stats=True)
+        scale, shift, _, _ = L.bn_finalize(stats, desc.N * desc.Hout * desc.Wout, bn, tr)
+        return L.bn_apply(y, scale, shift, L.ACT_RELU, res1, res2, out=y)
+
+    def forward(self, input, img_prev, mask, img_feat_coarse, flow_feat_coarse, img_fg_feat_coarse, use_raw_only):
+        self._check_inputs(input, img_prev)
+        dt, tr = self.compute_dtype, self.training
+        seg = self._encode(self.model_down_seg, input, dt, tr)
+        down_img = self._encode(self.model_down_img, img_prev, dt, tr, res1=seg)                   # (:290)
+        img_in = L.bn_apply_add(down_img, L.to_nhwc_half(img_feat_coarse, dt))                      # (:291)
+        img_feat = _run_sequence(self.model_up_img, img_in, dt, tr)
+        flow_feat = None
+        if not self.no_flow:
+            flow_in = L.bn_apply_add(down_img, L.to_nhwc_half(flow_feat_coarse, dt))                # (:297)
+            flow_feat = _run_sequence(self.model_up_flow, flow_in, dt, tr)
+        img_final, flow, weight, img_raw = self._heads_and_blend(img_feat, flow_feat, img_prev, use_raw_only,
+                                                                 20.0 * (2 ** self.scale))
+        return img_final, flow, weight, img_raw, img_feat, flow_feat, None
+
+
+# ---------------------------------------------------------------------------------------------
+# discriminators
+# ---------------------------------------------------------------------------------------------
+class NLayerDiscriminator(nn.Module):
+    """PatchGAN (reference networks.py:672-718): Conv4x4 s2 -> LReLU; (n_layers-1) x [Conv4x4 s2, BN,
+    LReLU]; [Conv4x4 s1, BN, LReLU]; Conv4x4 s1 -> 1 channel.  padding = ceil(3/2) = 2."""
+
+    def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer=nn.BatchNorm2d, getIntermFeat=False):
+        super().__init__()
+        _check_ngf(ndf)
+        self.getIntermFeat, self.n_layers = getIntermFeat, n_layers
+        kw, padw = 4, 2
+        groups = [[nn.Conv2d(input_nc, ndf, kernel_size=kw, stride=2, padding=padw), nn.LeakyReLU(0.2, True)]]
+        nf = ndf
+        for _ in range(1, n_layers):
+            nf_prev, nf = nf, min(nf * 2, 512)
+            groups.append([nn.Conv2d(nf_prev, nf, kernel_size=kw, stride=2, padding=padw), norm_layer(nf),
+                           nn.LeakyReLU(0.2, True)])
+        nf_prev, nf = nf, min(nf * 2, 512)
+        groups.append([nn.Conv2d(nf_prev, nf, kernel_size=kw, stride=1, padding=padw), norm_layer(nf),
+                       nn.LeakyReLU(0.2, True)])
+        groups.append([nn.Conv2d(nf, 1, kernel_size=kw, stride=1, padding=padw)])
+        if getIntermFeat:
+            for n, g in enumerate(groups):
+                setattr(self, "model" + str(n), _seq(g))
+        else:
+            self.model = _seq([m for g in groups for m in g])
+
+
+def _run_patchgan(groups, x_nchw, dtype, training):
+    """groups: list of nn.Sequential ([conv, (bn), (lrelu)]).  Returns every group's output (NHWC half,
+    the last one -- 1 channel -- as NCHW fp32)."""
+    outs = []
+    g0 = groups[0]
+    h = L.first_stage(x_nchw, g0[0], None, L.ACT_NONE, C.PAD_ZERO, dtype, fused_leaky=True, training=training)
+    outs.append(h)
+    for g in groups[1:-1]:
+        h = L.conv_stage(h, g[0], g[1], L.ACT_LEAKY, C.PAD_ZERO, training=training)
+        outs.append(h)
+    last = groups[-1][0]
+    desc = C.make_desc(tuple(h.shape), last.out_channels, 4, 1, 2, C.PAD_ZERO, h.dtype, out_f32=True)
+    y, _ = C.conv2d_fwd(desc, h, L.packed_weight(last, desc), last.bias)
+    outs.append(y)  # [N,1,H,W]: channels_last == contiguous for a single channel
+    return outs
+
+
+class MultiScaleDiscriminator(nn.Module):
+    """num_D PatchGANs on an average-pooled pyramid (reference networks.py:627-668)."""
+    compute_dtype = torch.bfloat16
+
+    def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer=nn.BatchNorm2d, num_D=3, getIntermFeat=False):
+        super().__init__()
+        self.num_D, self.n_layers, self.getIntermFeat = num_D, n_layers, getIntermFeat
+        ndf_max = 64
+        for i in range(num_D):
+            net = NLayerDiscriminator(input_nc, min(ndf_max, ndf * (2 ** (num_D - 1 - i))), n_layers, norm_layer,
+                                      getIntermFeat)
+            if getIntermFeat:
+                for j in range(n_layers + 2):
+                    setattr(self, f"scale{i}_layer{j}", getattr(net, "model" + str(j)))
+            else:
+                setattr(self, f"layer{i}", net.model)
+        self.downsample = nn.AvgPool2d(3, stride=2, padding=[1, 1], count_include_pad=False)
+
+    def _groups(self, i):
+        if self.getIntermFeat:
+            return [getattr(self, f"scale{i}_layer{j}") for j in range(self.n_layers + 2)]
+        flat = list(getattr(self, f"layer{i}"))
+        groups, cur = [], []
+        for m in flat:
+            if isinstance(m, nn.Conv2d) and cur:
+                groups.append(cur)
+                cur = []
+            cur.append(m)
+        groups.append(cur)
+        return groups
+
+    def forward(self, input):
+        if not input.is_cuda:
+            raise ValueError("ir2rgb_amd discriminators run on an AMD GPU only (no CPU fallback)")
+        result = []
+        x = input.float().contiguous()
+        for i in range(self.num_D):
+            outs = _run_patchgan(self._groups(self.num_D - 1 - i), x, self.compute_dtype, self.training)
+            result.append(outs if self.getIntermFeat else [outs[-1]])
+            if i != self.num_D - 1:
+                x = self.downsample(x)
+        return result
+
+
+# ---------------------------------------------------------------------------------------------
+# factories
+# ---------------------------------------------------------------------------------------------
+def build_generator_module(input_nc, output_nc, prev_output_nc, ngf, model_name, n_downsampling, norm, scale, **opt):
+    norm_layer = get_norm_layer(norm_type=norm)
+    if model_name == "composite":
+        generator = CompositeGeneratorModule(input_nc, output_nc, prev_output_nc, ngf, n_downsampling, opt["gen_blocks"],
+                                             opt["fg"], opt["no_flow"], norm_layer)
+    elif model_name == "composite-local":
+        generator = CompositeLocalGeneratorModule(input_nc, output_nc, prev_output_nc, ngf, n_downsampling,
+                                                  opt["n_blocks_local"], opt["fg"], opt["no_flow"], norm_layer,
+                                                  scale=scale)
+    elif model_name in ("global", "local", "global-with-features", "local-with-features", "encoder"):
+        raise NotImplementedError(f"generator '{model_name}' is outside the IR->RGB hot path (SURVEY section 2, row 1)")
+    else:
+        raise NotImplementedError(f"Generator model named {model_name} is not implemented")
+    generator.apply(weights_init)
+    return generator
+
+
+def build_discriminator_module(input_nc, ndf, n_layers_D, norm="instance", num_D=1, get_interm_feat=False):
+    norm_layer = get_norm_layer(norm_type=norm)
+    discriminator = MultiScaleDiscriminator(input_nc, ndf, n_layers_D, norm_layer, num_D, get_interm_feat)
+    discriminator.apply(weights_init)
+    return discriminator
