@@ -115,7 +115,7 @@ typedef struct ir2rgb_conv_desc {
     int Hout, Wout, Cout;   /* output [N,Hout,Wout,Cout] NHWC              */
     int kh, kw, stride_h, stride_w, pad_h, pad_w;
     int pad_mode;           /* 0: zero padding, 1: reflection padding (nn.ReflectionPad2d) */
-    int transposed;         /* 0: Conv2d, 1: ConvTranspose2d (stride 2; Hout/Wout carry output_padding) */
+    int transposed;         /* 0: Conv2d, 1: ConvTranspose2d (stride 1 or 2 per axis; Hout/Wout carry output_padding) */
     int dtype;              /* IR2RGB_BF16 or IR2RGB_F16: activations and packed weights */
     int act;                /* fused after bias: 0 none, 1 LeakyReLU(0.2) */
     int out_f32;            /* 0: y is half NHWC, 1: y is fp32 NHWC (head convolutions) */
@@ -176,6 +176,32 @@ int ir2rgb_head_finish(const float *T, const float *bias, float *out, int N, int
  * raw [N,3,H,W], prev [N,Cp,H,W] (its LAST 3 channels are warped), flow [N,2,H,W], w [N,1,H,W]. */
 int ir2rgb_warp_blend_fwd(const float *raw, const float *prev, const float *flow, const float *w, float *out,
                           float *warp_out, int N, int Cp, int H, int W, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Backward companions (HBM-bound).  The data gradient of every convolution is itself an
+ * ir2rgb_conv2d_fwd call (transposed <-> strided, flipped weights); these cover the rest of
+ * what torch.autograd + cuDNN do for the reference's loss.backward() (train_vid2vid.py:166-169).
+ * ------------------------------------------------------------------------------------------ */
+
+/* Rows of the `partial` scratch ([rows][2][C] fp32) needed by ir2rgb_bn_bwd (< 0: error;
+ * C must be a power of two in [64, 2048]). */
+int ir2rgb_bn_bwd_blocks(long npix, int C);
+
+/* Backward of activation + training-mode BatchNorm2d on NHWC half tensors:
+ *   g' = gz * act'(y*scale+shift);  dbeta = sum g';  dgamma = sum g'*yhat;
+ *   gy = scale * (g' - dbeta/n - yhat*dgamma/n),  yhat = (y-mean)*invstd.
+ * With scale == NULL (no norm layer): gy = gz * act'(y) and dbeta = sum gy (the bias gradient).
+ * act: 0 none, 1 ReLU, 2 LeakyReLU(0.2).  gy may alias gz. */
+int ir2rgb_bn_bwd(const void *gz, const void *y, const float *scale, const float *shift, const float *mean,
+                  const float *invstd, void *gy, float *dgamma, float *dbeta, float *partial, long npix, int C,
+                  int act, int dtype, void *stream);
+
+/* Adjoint of nn.ReflectionPad2d(pad): dxpad [N,H+2p,W+2p,C] -> dx [N,H,W,C] (NHWC half). */
+int ir2rgb_fold_reflect(const void *dxpad, void *dx, int N, int H, int W, int C, int pad, int dtype, void *stream);
+
+/* Adjoint of ir2rgb_xexpand: dxe [N,H,Wout,64] half -> din [N,Cin,H,W] fp32. */
+int ir2rgb_xexpand_bwd(const void *dxe, float *din, int N, int Cin, int H, int W, int Wout, int KW, int stride_w,
+                       int pad_w, int pad_mode, int dtype, void *stream);
 
 #ifdef __cplusplus
 }

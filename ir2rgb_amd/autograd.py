@@ -1,0 +1,363 @@
+"""torch.autograd bindings of the fused HIP stages (what ``loss.backward()`` walks).
+
+Each stage of ir2rgb_amd.layers gets a ``torch.autograd.Function`` whose backward is again a
+short sequence of libir2rgb_hip.so calls:
+
+    gz --bn_bwd--> gy (grad wrt conv output), dgamma, dbeta
+    gy --conv2d_fwd with the adjoint geometry (+ fold_reflect / xexpand_bwd)--> dx
+    (x, gy) --wgrad--> dW
+
+Status of the pieces (see DESIGN.md "what is hand-written"): activation/BatchNorm backward, all
+data gradients, reflection fold and x-im2col adjoint are HIP.  The weight gradient, the head
+convolutions' backward and the warp-blend backward still go through torch operators on the GPU
+(``aten.convolution_backward`` / autograd recompute) -- marked INTERIM below; they compute the
+same quantities and are being replaced kernel by kernel.
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from . import _lib
+from . import conv as C
+from . import layers as L
+
+_DT = {torch.bfloat16: 1, torch.float16: 2}
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _as_half_nhwc(g, dtype):
+    if g.dtype == dtype and C.is_nhwc(g):
+        return g
+    if g.dtype == torch.float32:
+        return L.to_nhwc_half(g, dtype)
+    return g.to(dtype).contiguous(memory_format=torch.channels_last)
+
+
+def bn_bwd(gz, y, scale, shift, mean, invstd, act):
+    """-> (gy, dgamma, dbeta).  scale None: activation-only stage (dbeta is then the bias gradient)."""
+    n, ch, h, w = y.shape
+    npix = n * h * w
+    lib = _lib.lib()
+    nblk = lib.ir2rgb_bn_bwd_blocks(npix, ch)
+    if nblk < 0:
+        _lib.check(nblk, "bn_bwd_blocks")
+    dev = y.device
+    partial = torch.empty((nblk, 2, ch), dtype=torch.float32, device=dev)
+    dgamma = torch.empty(ch, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(ch, dtype=torch.float32, device=dev)
+    gy = torch.empty_like(y, memory_format=torch.channels_last)
+    with torch.cuda.device_of(y):
+        rc = lib.ir2rgb_bn_bwd(_p(gz), _p(y), _p(scale), _p(shift), _p(mean), _p(invstd), _p(gy), _p(dgamma), _p(dbeta),
+                               _p(partial), npix, ch, act, _DT[y.dtype], _lib.current_stream(y))
+    _lib.check(rc, "bn_bwd")
+    return gy, dgamma, dbeta
+
+
+def fold_reflect(dxpad, pad):
+    n, ch, hp, wp = dxpad.shape
+    h, w = hp - 2 * pad, wp - 2 * pad
+    dx = C.empty_nhwc(n, ch, h, w, dxpad.dtype, dxpad.device)
+    with torch.cuda.device_of(dxpad):
+        rc = _lib.lib().ir2rgb_fold_reflect(_p(dxpad), _p(dx), n, h, w, ch, pad, _DT[dxpad.dtype],
+                                            _lib.current_stream(dxpad))
+    _lib.check(rc, "fold_reflect")
+    return dx
+
+
+def xexpand_bwd(dxe, cin, w, kw, stride_w, pad_w, pad_mode):
+    n, _, h, wout = dxe.shape
+    din = torch.empty((n, cin, h, w), dtype=torch.float32, device=dxe.device)
+    with torch.cuda.device_of(dxe):
+        rc = _lib.lib().ir2rgb_xexpand_bwd(_p(dxe), _p(din), n, cin, h, w, wout, kw, stride_w, pad_w, pad_mode,
+                                           _DT[dxe.dtype], _lib.current_stream(dxe))
+    _lib.check(rc, "xexpand_bwd")
+    return din
+
+
+# ---------------------------------------------------------------------------------------------
+# data gradient = a forward convolution with the adjoint geometry
+# ---------------------------------------------------------------------------------------------
+def _flip_swap(w):
+    """Conv2d weight [Cout,Cin,kh,kw] -> adjoint Conv2d weight [Cin,Cout,kh,kw] (taps reversed)."""
+    return w.permute(1, 0, 2, 3).flip(2, 3)
+
+
+def _compose(f, g):
+    if f is None:
+        return g
+    if g is None:
+        return f
+    return lambda w: g(f(w))
+
+
+def conv_dgrad(gy, conv, spec, x_shape, weight_fn=None, tag="dgrad"):
+    """gy: grad wrt the convolution output (channels_last half, channels % 64 == 0).  ``weight_fn``
+    maps conv.weight to the weight tensor the forward convolution actually used (x-expanded / padded
+    forms).  Returns grad wrt the convolution input (channels_last half)."""
+    kh, kw = spec["k"]
+    (sh, sw), (ph, pw) = spec["stride"], spec["pad"]
+    n, cin, hin, win = x_shape
+    dt = gy.dtype
+    if spec["transposed"]:
+        # forward was ConvTranspose2d(W[cin][cout]); adjoint = Conv2d with the same memory as [out=cin][in=cout]
+        desc = C.make_desc(tuple(gy.shape), cin, (kh, kw), (sh, sw), (ph, pw), C.PAD_ZERO, dt)
+        wp = L.packed_weight(conv, desc, weight_fn, tag=tag)
+        dx, _ = C.conv2d_fwd(desc, gy, wp)
+        return dx
+    if sh == 1 and sw == 1:
+        if spec["pad_mode"] == C.PAD_REFLECT:
+            desc = C.make_desc(tuple(gy.shape), cin, (kh, kw), 1, (kh - 1, kw - 1), C.PAD_ZERO, dt)
+            wp = L.packed_weight(conv, desc, _compose(weight_fn, _flip_swap), tag=tag)
+            dxpad, _ = C.conv2d_fwd(desc, gy, wp)
+            return fold_reflect(dxpad, ph) if ph == pw and ph > 0 else dxpad
+        desc = C.make_desc(tuple(gy.shape), cin, (kh, kw), 1, (kh - 1 - ph, kw - 1 - pw), C.PAD_ZERO, dt)
+        wp = L.packed_weight(conv, desc, _compose(weight_fn, _flip_swap), tag=tag)
+        dx, _ = C.conv2d_fwd(desc, gy, wp)
+        return dx
+    # strided zero-padded convolution: adjoint = transposed convolution reading W as [in=cout][out=cin]
+    if spec["pad_mode"] != C.PAD_ZERO:
+        raise NotImplementedError("data gradient of a strided reflect-padded convolution")
+    hfull, wfull = (gy.shape[2] - 1) * sh - 2 * ph + kh, (gy.shape[3] - 1) * sw - 2 * pw + kw
+    desc = C.ConvDesc(n, gy.shape[2], gy.shape[3], gy.shape[1], hin, win, cin, kh, kw, sh, sw, ph, pw, C.PAD_ZERO, 1,
+                      _DT[dt], 0, 0)
+    assert 0 <= hin - hfull < sh and 0 <= win - wfull < sw, "adjoint geometry mismatch"
+    wp = L.packed_weight(conv, desc, weight_fn, tag=tag)
+    dx, _ = C.conv2d_fwd(desc, gy, wp)
+    return dx
+
+
+# ---------------------------------------------------------------------------------------------
+# weight gradient -- INTERIM: torch (MIOpen) wgrad on the same half NHWC tensors
+# ---------------------------------------------------------------------------------------------
+def conv_wgrad(x, gy, weight_shape, spec):
+    kh, kw = spec["k"]
+    stride, pad = list(spec["stride"]), list(spec["pad"])
+    if spec["pad_mode"] == C.PAD_REFLECT and (pad[0] or pad[1]):
+        x = F.pad(x, (pad[1], pad[1], pad[0], pad[0]), mode="reflect")
+        pad = [0, 0]
+    wlike = torch.empty(weight_shape, dtype=x.dtype, device=x.device).contiguous(memory_format=torch.channels_last)
+    opad = [spec.get("output_padding", 0)] * 2
+    gw = torch.ops.aten.convolution_backward(gy, x, wlike, None, stride, pad, [1, 1], bool(spec["transposed"]),
+                                             opad if spec["transposed"] else [0, 0], 1, [False, True, False])[1]
+    return gw.float()
+
+
+# ---------------------------------------------------------------------------------------------
+# the fused stage
+# ---------------------------------------------------------------------------------------------
+class ConvStageFn(Function):
+    """z = act(bn(conv(x))) + res1 + res2 on channels_last half tensors (x may be an NCHW fp32 image
+    for 'first' stages).  Arguments after ``x``: weight, bias, gamma, beta (fp32 parameters), res1,
+    res2, then the non-tensor ``spec`` dict and the conv / bn modules (packed-weight cache, BN
+    buffers)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, res1, res2, spec, conv, bn):
+        dt = spec["dtype"]
+        first = spec["first"]
+        if first:
+            kh, kw = conv.kernel_size
+            xin = L.xexpand(x, kw, spec["stride"][1], spec["pad"][1], spec["pad_mode"], dt)
+            desc = C.make_desc(tuple(xin.shape), conv.out_channels, (kh, 1), (spec["stride"][0], 1), (spec["pad"][0], 0),
+                               spec["pad_mode"], dt, act=1 if spec["fused_leaky"] else 0)
+            wp = L.packed_weight(conv, desc, L._xexpanded_weight(kw), tag="xexp")
+        else:
+            xin = x
+            desc = C.make_desc(tuple(x.shape), conv.out_channels, spec["k"], spec["stride"], spec["pad"], spec["pad_mode"],
+                               dt, spec["transposed"], spec.get("output_padding", 0), act=1 if spec["fused_leaky"] else 0,
+                               out_f32=spec.get("out_f32", False))
+            wp = L.packed_weight(conv, desc)
+        y, stats = C.conv2d_fwd(desc, xin, wp, bias, want_stats=bn is not None)
+        scale = shift = mean = invstd = None
+        if bn is not None:
+            scale, shift, mean, invstd = L.bn_finalize(stats, desc.N * desc.Hout * desc.Wout, bn, spec["training"])
+            z = L.bn_apply(y, scale, shift, spec["act"], res1, res2)
+        else:
+            z = y
+        ctx.spec, ctx.conv = spec, conv
+        ctx.x_shape = tuple(x.shape)
+        ctx.has_bn = bn is not None
+        ctx.has_res = (res1 is not None, res2 is not None)
+        ctx.save_for_backward(xin, y, scale, shift, mean, invstd)
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        spec, conv = ctx.spec, ctx.conv
+        xin, y, scale, shift, mean, invstd = ctx.saved_tensors
+        hdt = xin.dtype
+        pad_fn = None
+        if spec.get("out_f32", False):
+            # thin fp32 output (PatchGAN logits): pad the gradient to 64 channels for the MFMA adjoint
+            cout = y.shape[1]
+            dbias = gz.float().sum((0, 2, 3))
+            gy_thin = gz.to(hdt).contiguous(memory_format=torch.channels_last)
+            gy = torch.zeros((gz.shape[0], 64, gz.shape[2], gz.shape[3]), dtype=hdt, device=gz.device).contiguous(
+                memory_format=torch.channels_last)
+            gy[:, :cout] = gy_thin
+            pad_fn = lambda w: torch.cat([w, w.new_zeros((64 - w.shape[0],) + tuple(w.shape[1:]))], 0)  # noqa: E731
+            dgamma = dbeta = None
+        elif ctx.has_bn:
+            gz = _as_half_nhwc(gz, hdt)
+            gy, dgamma, dbeta = bn_bwd(gz, y, scale, shift, mean, invstd, spec["act"])
+            gy_thin = gy
+            dbias = torch.zeros(y.shape[1], dtype=torch.float32, device=y.device)  # BN removes the mean: exactly 0
+        else:
+            gz = _as_half_nhwc(gz, hdt)
+            act = 2 if spec["fused_leaky"] else 0  # LeakyReLU keeps the sign: mask from the stored output
+            gy, _, dbias = bn_bwd(gz, y, None, None, None, None, act)
+            gy_thin = gy
+            dgamma = dbeta = None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if spec["first"]:
+                kh, kw = conv.kernel_size
+                sub = dict(spec, k=(kh, 1), stride=(spec["stride"][0], 1), pad=(spec["pad"][0], 0))
+                if spec["pad_mode"] != C.PAD_ZERO:
+                    raise NotImplementedError("input gradient of a reflect-padded first layer is never needed")
+                # adjoint of the (kh x 1) convolution over the expanded image, then of the x-im2col
+                n, _, h, wout = xin.shape
+                dxe = conv_dgrad(gy, conv, sub, (n, 64, h, wout), L._xexpanded_weight(kw), tag="dgrad_xexp")
+                dx = xexpand_bwd(dxe, ctx.x_shape[1], ctx.x_shape[3], kw, spec["stride"][1], spec["pad"][1],
+                                 spec["pad_mode"])
+            else:
+                dx = conv_dgrad(gy, conv, spec, ctx.x_shape, pad_fn)
+        gy = gy_thin
+        dw = None
+        if ctx.needs_input_grad[1]:
+            if spec["first"]:
+                kh, kw = conv.kernel_size
+                sub = dict(spec, k=(kh, 1), stride=(spec["stride"][0], 1), pad=(spec["pad"][0], 0))
+                gwe = conv_wgrad(xin, gy, (conv.out_channels, 64, kh, 1), sub)      # [co][64][kh][1]
+                cin = conv.in_channels
+                gwe = gwe[:, :cin * kw, :, 0].reshape(conv.out_channels, cin, kw, kh)  # [co][ci][kx][ky]
+                dw = gwe.permute(0, 1, 3, 2).contiguous()
+            else:
+                dw = conv_wgrad(xin, gy, tuple(conv.weight.shape), spec)
+        r1 = gz if ctx.has_res[0] else None
+        r2 = gz if ctx.has_res[1] else None
+        return dx, dw, (dbias if ctx.needs_input_grad[2] else None), dgamma, dbeta, r1, r2, None, None, None
+
+
+def conv_stage(x, conv, bn, act, pad_mode, dtype, *, first=False, stride=None, pad=None, transposed=False,
+               output_padding=0, res1=None, res2=None, fused_leaky=False, training=True, out_f32=False):
+    """Autograd-aware stage: act(bn(conv(x))) + res1 + res2 (bn may be None)."""
+    stride = tuple(conv.stride) if stride is None else C._pair(stride)
+    pad = tuple(conv.padding) if pad is None else C._pair(pad)
+    spec = dict(k=tuple(conv.kernel_size), stride=stride, pad=pad, pad_mode=pad_mode, transposed=transposed,
+                output_padding=output_padding, act=act, fused_leaky=fused_leaky, training=training, dtype=dtype,
+                first=first, out_f32=out_f32)
+    gamma = bn.weight if bn is not None else None
+    beta = bn.bias if bn is not None else None
+    return ConvStageFn.apply(x, conv.weight, conv.bias, gamma, beta, res1, res2, spec, conv, bn)
+
+
+# ---------------------------------------------------------------------------------------------
+# heads and warp-blend: HIP forward; backward INTERIM through torch autograd recompute
+# ---------------------------------------------------------------------------------------------
+class HeadFn(Function):
+    @staticmethod
+    def forward(ctx, feat, acts, mul, convs, *params):
+        ctx.acts, ctx.mul, ctx.convs = acts, mul, convs
+        ctx.save_for_backward(feat, *params)
+        return L.head_stage(feat, convs, acts, mul)
+
+    @staticmethod
+    def backward(ctx, gout):
+        feat, *params = ctx.saved_tensors
+        nconv = len(ctx.convs)
+        ws, bs = params[:nconv], params[nconv:]
+        with torch.enable_grad():
+            f = feat.detach().float().requires_grad_(ctx.needs_input_grad[0])
+            wl = [w.detach().requires_grad_() for w in ws]
+            bl = [b.detach().requires_grad_() for b in bs]
+            pre = F.conv2d(F.pad(f, (3, 3, 3, 3), mode="reflect"), torch.cat(wl, 0), torch.cat(bl, 0))
+            outs = []
+            for i, a in enumerate(ctx.acts):
+                ch = pre[:, i:i + 1]
+                outs.append(torch.tanh(ch) if a == 1 else (torch.sigmoid(ch) if a == 2 else ch * ctx.mul))
+            out = torch.cat(outs, 1)
+            wanted = ([f] if ctx.needs_input_grad[0] else []) + wl + bl
+            grads = torch.autograd.grad(out, wanted, gout.float())
+        gi = 0
+        gfeat = None
+        if ctx.needs_input_grad[0]:
+            gfeat = grads[0].to(feat.dtype).contiguous(memory_format=torch.channels_last)
+            gi = 1
+        return (gfeat, None, None, None) + tuple(grads[gi:])
+
+
+def head_stage(feat, convs, acts, mul=1.0):
+    params = [c.weight for c in convs] + [c.bias for c in convs]
+    return HeadFn.apply(feat, list(acts), float(mul), list(convs), *params)
+
+
+class WarpBlendFn(Function):
+    @staticmethod
+    def forward(ctx, raw, prev, flow, weight):
+        ctx.save_for_backward(raw, prev, flow, weight)
+        return L.warp_blend(raw.contiguous(), prev.contiguous(), flow.contiguous(), weight.contiguous())
+
+    @staticmethod
+    def backward(ctx, gout):
+        raw, prev, flow, weight = ctx.saved_tensors
+        from .networks import get_grid
+        with torch.enable_grad():
+            ins = [t.detach().requires_grad_(ctx.needs_input_grad[i]) for i, t in enumerate((raw, prev, flow, weight))]
+            r, p, fl, w = ins
+            b, _, h, wd = r.shape
+            grid = get_grid(b, h, wd, device=r.device, dtype=fl.dtype)
+            fln = torch.cat([fl[:, 0:1] / ((wd - 1.0) / 2.0), fl[:, 1:2] / ((h - 1.0) / 2.0)], 1)
+            warp = F.grid_sample(p[:, -3:], (grid + fln).permute(0, 2, 3, 1), mode="bilinear", padding_mode="border",
+                                 align_corners=False)
+            out = r * w + warp * (1 - w)
+            wanted = [t for i, t in enumerate(ins) if ctx.needs_input_grad[i]]
+            grads = list(torch.autograd.grad(out, wanted, gout)) if wanted else []
+        res = []
+        for i in range(4):
+            res.append(grads.pop(0) if ctx.needs_input_grad[i] else None)
+        return tuple(res)
+
+
+def warp_blend(raw, prev, flow, weight):
+    return WarpBlendFn.apply(raw, prev, flow, weight)
+
+
+class AddFn(Function):
+    """a + b on channels_last half tensors (HIP), gradient passed to both."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        return L.bn_apply_add(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    return AddFn.apply(a, b)
+
+
+class ToHalfFn(Function):
+    """NCHW fp32 (or any) -> channels_last half (HIP converter); backward converts the gradient back."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src_dtype = x.dtype
+        return L.to_nhwc_half(x, dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (L.to_nchw_f32(g) if ctx.src_dtype == torch.float32 else g.to(ctx.src_dtype)), None
+
+
+def to_nhwc_half(x, dtype):
+    if x.dtype == dtype and C.is_nhwc(x):
+        return x
+    return ToHalfFn.apply(x, dtype)

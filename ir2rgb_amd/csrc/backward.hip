@@ -1,0 +1,245 @@
+// backward.hip -- HBM-bound backward companions of the MFMA convolution (gfx950):
+//   * bn_bwd_reduce / bn_bwd_finalize / bn_bwd_apply : backward of activation + training-mode
+//     BatchNorm2d on NHWC half tensors, producing the gradient w.r.t. the convolution output
+//     plus dgamma / dbeta (and the bias gradient of norm-less stages);
+//   * fold_reflect : adjoint of nn.ReflectionPad2d -- folds the border of the padded-domain
+//     gradient produced by the data-gradient convolution back into the image;
+//   * xexpand_bwd  : adjoint of the x-direction im2col of the first layers.
+// Reductions are two-level and deterministic (per-block partial rows, then a finalize kernel).
+#include "common.h"
+
+static __device__ __forceinline__ float h2f(uint16_t h, int dt) {
+    if (dt == IR2RGB_BF16) return __uint_as_float(((uint32_t)h) << 16);
+    _Float16 v = __builtin_bit_cast(_Float16, h);
+    return (float)v;
+}
+static __device__ __forceinline__ uint16_t f2h(float f, int dt) {
+    if (dt == IR2RGB_BF16) { __bf16 h = (__bf16)f; return __builtin_bit_cast(uint16_t, h); }
+    _Float16 h = (_Float16)f;
+    return __builtin_bit_cast(uint16_t, h);
+}
+
+__device__ __forceinline__ void unpack8(const uint4 &v, float *f, int dt) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f[2 * j] = h2f((uint16_t)(w[j] & 0xffff), dt);
+        f[2 * j + 1] = h2f((uint16_t)(w[j] >> 16), dt);
+    }
+}
+__device__ __forceinline__ uint4 pack8(const float *f, int dt) {
+    uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = (uint32_t)f2h(f[2 * j], dt) | ((uint32_t)f2h(f[2 * j + 1], dt) << 16);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// g' = gz * act'(pre) where pre = y*scale+shift (BN output) or y itself (scale == nullptr)
+__device__ __forceinline__ float act_grad(float g, float pre, int act) {
+    if (act == 1) return pre > 0.f ? g : 0.f;
+    if (act == 2) return pre > 0.f ? g : 0.2f * g;
+    return g;
+}
+
+// partial[blk][0][c] = sum g', partial[blk][1][c] = sum g' * yhat over this block's pixels.
+// Block = 256 threads; thread t owns channel octet t % (C/8) and pixel rows t / (C/8) + k*(256/(C/8)).
+__global__ void __launch_bounds__(256)
+bn_bwd_reduce_kernel(const uint4 *__restrict__ gz, const uint4 *__restrict__ y, const float *__restrict__ scale,
+                     const float *__restrict__ shift, const float *__restrict__ mean, const float *__restrict__ invstd,
+                     float *__restrict__ partial, long npix, int C, int act, int dt, long pix_per_block) {
+    __shared__ float red[2][256][9];  // [which][thread][8 (+1 pad)]
+    const int octs = C >> 3, rows = 256 / octs;
+    const int oc = threadIdx.x % octs, r0 = threadIdx.x / octs;
+    const long p_begin = (long)blockIdx.x * pix_per_block;
+    const long p_end = min(npix, p_begin + pix_per_block);
+    float s1[8], s2[8], sc[8], sh[8], mu[8], is[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        s1[j] = s2[j] = 0.f;
+        const int c = oc * 8 + j;
+        sc[j] = scale ? scale[c] : 1.f;
+        sh[j] = shift ? shift[c] : 0.f;
+        mu[j] = mean ? mean[c] : 0.f;
+        is[j] = invstd ? invstd[c] : 1.f;
+    }
+    for (long p = p_begin + r0; p < p_end; p += rows) {
+        float g[8], v[8];
+        unpack8(gz[p * octs + oc], g, dt);
+        unpack8(y[p * octs + oc], v, dt);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float gp = act_grad(g[j], v[j] * sc[j] + sh[j], act);
+            s1[j] += gp;
+            s2[j] += gp * (v[j] - mu[j]) * is[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[0][threadIdx.x][j] = s1[j]; red[1][threadIdx.x][j] = s2[j]; }
+    __syncthreads();
+    // thread t < 2*C: which = t / C, channel c = t % C  (2*C may exceed 256: loop)
+    for (int t = threadIdx.x; t < 2 * C; t += 256) {
+        const int which = t / C, c = t - which * C, o = c >> 3, j = c & 7;
+        float s = 0.f;
+        for (int r = 0; r < rows; ++r) s += red[which][r * octs + o][j];
+        partial[((long)blockIdx.x * 2 + which) * C + c] = s;
+    }
+}
+
+// dbeta[c] = sum_blocks partial[.][0][c], dgamma[c] = sum_blocks partial[.][1][c]
+__global__ void __launch_bounds__(256)
+bn_bwd_finalize_kernel(const float *__restrict__ partial, int nblk, int C, float *__restrict__ dgamma,
+                       float *__restrict__ dbeta) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int r = 0; r < nblk; ++r) {
+        a += (double)partial[((long)r * 2 + 0) * C + c];
+        b += (double)partial[((long)r * 2 + 1) * C + c];
+    }
+    dbeta[c] = (float)a;
+    dgamma[c] = (float)b;
+}
+
+// gy = scale * (g' - dbeta/n - yhat * dgamma/n)     (BatchNorm stage)
+// gy = g'                                            (scale == nullptr: activation only)
+__global__ void __launch_bounds__(256)
+bn_bwd_apply_kernel(const uint4 *__restrict__ gz, const uint4 *__restrict__ y, const float *__restrict__ scale,
+                    const float *__restrict__ shift, const float *__restrict__ mean, const float *__restrict__ invstd,
+                    const float *__restrict__ dgamma, const float *__restrict__ dbeta, uint4 *__restrict__ gy,
+                    long total8, int C8, float inv_n, int act, int dt) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total8; i += (long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % C8) * 8;
+        float g[8], v[8], o[8];
+        unpack8(gz[i], g, dt);
+        unpack8(y[i], v, dt);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c0 + j;
+            if (scale) {
+                const float sc = scale[c];
+                float gp = act_grad(g[j], v[j] * sc + shift[c], act);
+                float yh = (v[j] - mean[c]) * invstd[c];
+                o[j] = sc * (gp - dbeta[c] * inv_n - yh * dgamma[c] * inv_n);
+            } else {
+                o[j] = act_grad(g[j], v[j], act);
+            }
+        }
+        gy[i] = pack8(o, dt);
+    }
+}
+
+// dx[n][y][x][c] = sum over padded positions (py,px) that reflect onto (y,x) of dxpad[n][py][px][c]
+__global__ void __launch_bounds__(256)
+fold_reflect_kernel(const uint4 *__restrict__ dxpad, uint4 *__restrict__ dx, int H, int W, int C8, int pad,
+                    long total8, int dt) {
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total8; i += (long)gridDim.x * blockDim.x) {
+        long r = i;
+        const int c8 = (int)(r % C8); r /= C8;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H);
+        const long n = r / H;
+        // candidate padded rows: y+pad (identity), pad-y (top mirror, 1<=y<=pad), pad+2H-2-y (bottom mirror)
+        int ys[3], xs[3], ny = 0, nx = 0;
+        ys[ny++] = y + pad;
+        if (y >= 1 && y <= pad) ys[ny++] = pad - y;
+        if (y <= H - 2 && y >= H - 1 - pad) ys[ny++] = pad + 2 * H - 2 - y;
+        xs[nx++] = x + pad;
+        if (x >= 1 && x <= pad) xs[nx++] = pad - x;
+        if (x <= W - 2 && x >= W - 1 - pad) xs[nx++] = pad + 2 * W - 2 - x;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int a = 0; a < ny; ++a)
+            for (int b = 0; b < nx; ++b) {
+                float f[8];
+                unpack8(dxpad[((n * Hp + ys[a]) * (long)Wp + xs[b]) * C8 + c8], f, dt);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += f[j];
+            }
+        dx[i] = pack8(acc, dt);
+    }
+}
+
+// din[n][ci][y][ix] = sum_{kx, ox : pad(ox*sx + kx - px) == ix} dxe[n][y][ox][ci*KW + kx]   (fp32 NCHW out)
+__global__ void __launch_bounds__(256)
+xexpand_bwd_kernel(const uint16_t *__restrict__ dxe, float *__restrict__ din, int Cin, int H, int W, int Wout, int KW,
+                   int sx, int px, int pad_mode, long total, int dt) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r = i;
+        const int ix = (int)(r % W); r /= W;
+        const int y = (int)(r % H); r /= H;
+        const int ci = (int)(r % Cin);
+        const long n = r / Cin;
+        float acc = 0.f;
+        for (int kx = 0; kx < KW; ++kx) {
+            // unpadded source positions that map to ix: ix itself, and its mirror images under reflection
+            int cand[3], nc = 0;
+            cand[nc++] = ix;
+            if (pad_mode) {
+                if (ix >= 1) cand[nc++] = -ix;
+                if (ix <= W - 2) cand[nc++] = 2 * W - 2 - ix;
+            }
+            for (int q = 0; q < nc; ++q) {
+                int t = cand[q] + px - kx;  // = ox * sx
+                if (t < 0 || (t % sx) != 0) continue;
+                int ox = t / sx;
+                if (ox >= Wout) continue;
+                int src = ox * sx + kx - px;  // must lie inside the padded range actually read in forward
+                if (src < -px || src > W - 1 + px) continue;
+                acc += h2f(dxe[((n * H + y) * (long)Wout + ox) * 64 + ci * KW + kx], dt);
+            }
+        }
+        din[i] = acc;
+    }
+}
+
+extern "C" int ir2rgb_bn_bwd_blocks(long npix, int C) {
+    if (npix < 1 || C < 64 || (C & (C - 1)) || C > 2048) return IR2RGB_EINVAL;
+    long per = 256;  // pixels per block, grown until <= 1024 blocks
+    while ((npix + per - 1) / per > 1024) per *= 2;
+    return (int)((npix + per - 1) / per);
+}
+
+extern "C" int ir2rgb_bn_bwd(const void *gz, const void *y, const float *scale, const float *shift, const float *mean,
+                             const float *invstd, void *gy, float *dgamma, float *dbeta, float *partial, long npix,
+                             int C, int act, int dtype, void *stream) {
+    int nblk = ir2rgb_bn_bwd_blocks(npix, C);
+    if (nblk < 0) return nblk;
+    if (dtype != IR2RGB_BF16 && dtype != IR2RGB_F16) return IR2RGB_ENOSUP;
+    if (!gz || !y || !gy || !dgamma || !dbeta || !partial || act < 0 || act > 2) return IR2RGB_EINVAL;
+    long per = (npix + nblk - 1) / nblk;
+    // per must match the partition used to size `partial`: recompute exactly as ir2rgb_bn_bwd_blocks did
+    per = 256;
+    while ((npix + per - 1) / per > 1024) per *= 2;
+    hipStream_t s = as_stream(stream);
+    bn_bwd_reduce_kernel<<<nblk, 256, 0, s>>>((const uint4 *)gz, (const uint4 *)y, scale, shift, mean, invstd, partial,
+                                              npix, C, act, dtype, per);
+    bn_bwd_finalize_kernel<<<cdiv(C, 256), 256, 0, s>>>(partial, nblk, C, dgamma, dbeta);
+    long total8 = npix * (C / 8);
+    bn_bwd_apply_kernel<<<stream_grid(total8, 256), 256, 0, s>>>((const uint4 *)gz, (const uint4 *)y, scale, shift, mean,
+                                                                 invstd, dgamma, dbeta, (uint4 *)gy, total8, C / 8,
+                                                                 1.0f / (float)npix, act, dtype);
+    return ir2rgb_launch_status();
+}
+
+extern "C" int ir2rgb_fold_reflect(const void *dxpad, void *dx, int N, int H, int W, int C, int pad, int dtype,
+                                   void *stream) {
+    if (N < 0 || H < 2 || W < 2 || C < 8 || (C % 8) || pad < 0 || pad >= H || pad >= W) return IR2RGB_EINVAL;
+    if (dtype != IR2RGB_BF16 && dtype != IR2RGB_F16) return IR2RGB_ENOSUP;
+    long total8 = (long)N * H * W * (C / 8);
+    if (total8 == 0) return IR2RGB_OK;
+    fold_reflect_kernel<<<stream_grid(total8, 256), 256, 0, as_stream(stream)>>>((const uint4 *)dxpad, (uint4 *)dx, H, W,
+                                                                                 C / 8, pad, total8, dtype);
+    return ir2rgb_launch_status();
+}
+
+extern "C" int ir2rgb_xexpand_bwd(const void *dxe, float *din, int N, int Cin, int H, int W, int Wout, int KW,
+                                  int stride_w, int pad_w, int pad_mode, int dtype, void *stream) {
+    if (N < 0 || Cin < 1 || H < 1 || W < 1 || Wout < 1 || KW < 1 || Cin * KW > 64 || stride_w < 1 || pad_w < 0)
+        return IR2RGB_EINVAL;
+    if (dtype != IR2RGB_BF16 && dtype != IR2RGB_F16) return IR2RGB_ENOSUP;
+    long total = (long)N * Cin * H * W;
+    if (total == 0) return IR2RGB_OK;
+    xexpand_bwd_kernel<<<stream_grid(total, 256), 256, 0, as_stream(stream)>>>((const uint16_t *)dxe, din, Cin, H, W, Wout,
+                                                                               KW, stride_w, pad_w, pad_mode, total, dtype);
+    return ir2rgb_launch_status();
+}

@@ -44,7 +44,7 @@ struct ConvGeom {
     int Hsub, Wsub;           // sub-grid of output positions computed by this launch
     int Hout, Wout, Cout;
     int s_in_y, s_in_x;       // input coordinate  = sub * s_in  + tap offset
-    int s_out, off_y, off_x;  // output coordinate = sub * s_out + off
+    int s_out_y, s_out_x, off_y, off_x;  // output coordinate = sub * s_out + off
     int ntaps, pad_mode;      // pad_mode 0: zeros outside, 1: reflect (no edge repeat)
     int kchunks;              // Cin / 64
     int act;                  // 0: none, 1: LeakyReLU(0.2) after bias
@@ -301,7 +301,7 @@ conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W
         p = oval[ni] ? p : 0u;
         unsigned n = p / HW, rem = p - n * HW;
         unsigned sy = rem / (unsigned)g.Wsub, sx = rem - sy * g.Wsub;
-        opix[ni] = ((long)n * g.Hout + (sy * g.s_out + g.off_y)) * g.Wout + (sx * g.s_out + g.off_x);
+        opix[ni] = ((long)n * g.Hout + (sy * g.s_out_y + g.off_y)) * g.Wout + (sx * g.s_out_x + g.off_x);
     }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
@@ -439,7 +439,7 @@ static int make_plan(const ir2rgb_conv_desc *d, ClassPlan plans[4]) {
         g = ConvGeom{};
         g.N = d->N; g.Hin = d->Hin; g.Win = d->Win; g.Cin = d->Cin;
         g.Hsub = Ho; g.Wsub = Wo; g.Hout = Ho; g.Wout = Wo; g.Cout = d->Cout;
-        g.s_in_y = d->stride_h; g.s_in_x = d->stride_w; g.s_out = 1; g.off_y = g.off_x = 0;
+        g.s_in_y = d->stride_h; g.s_in_x = d->stride_w; g.s_out_y = g.s_out_x = 1; g.off_y = g.off_x = 0;
         g.ntaps = d->kh * d->kw; g.pad_mode = d->pad_mode; g.kchunks = d->Cin / 64; g.act = d->act;
         g.out_f32 = d->out_f32;
         c.pack = PackGeom{};
@@ -453,34 +453,37 @@ static int make_plan(const ir2rgb_conv_desc *d, ClassPlan plans[4]) {
         c.w_offset = 0;
         ncls = 1;
     } else {
-        // stride-2 transposed convolution as 4 sub-pixel (output parity) classes:
-        //   oy = 2*iy - pad + ky  ->  for oy = 2*sy + a: ky = (a + pad) mod 2 (+2j), iy = sy + (a + pad - ky)/2
-        if (d->stride_h != 2 || d->stride_w != 2 || d->pad_mode != 0) return IR2RGB_ENOSUP;
-        if ((d->Hout & 1) || (d->Wout & 1) || d->Hout / 2 < 1) return IR2RGB_EINVAL;
-        int Hfull = (d->Hin - 1) * 2 - 2 * d->pad_h + d->kh, Wfull = (d->Win - 1) * 2 - 2 * d->pad_w + d->kw;
-        if (d->Hout < Hfull || d->Hout > Hfull + 1 || d->Wout < Wfull || d->Wout > Wfull + 1) return IR2RGB_EINVAL;
-        for (int a = 0; a < 2; ++a)
-            for (int b = 0; b < 2; ++b) {
+        // transposed convolution (stride 1 or 2 per axis) as stride_h*stride_w sub-pixel classes:
+        //   oy = sh*iy - pad + ky  ->  for oy = sh*sy + a: ky = (a + pad) mod sh (+ sh*j), iy = sy + (a + pad - ky)/sh
+        const int sh = d->stride_h, sw = d->stride_w;
+        if (sh > 2 || sw > 2 || d->pad_mode != 0) return IR2RGB_ENOSUP;
+        int Hfull = (d->Hin - 1) * sh - 2 * d->pad_h + d->kh, Wfull = (d->Win - 1) * sw - 2 * d->pad_w + d->kw;
+        if (d->Hout < Hfull || d->Hout > Hfull + sh - 1 || d->Wout < Wfull || d->Wout > Wfull + sw - 1 || d->Hout < 1 ||
+            d->Wout < 1)
+            return IR2RGB_EINVAL;
+        for (int a = 0; a < sh; ++a)
+            for (int b = 0; b < sw; ++b) {
+                const int Hsub = (d->Hout - a + sh - 1) / sh, Wsub = (d->Wout - b + sw - 1) / sw;
+                if (Hsub < 1 || Wsub < 1) continue;
                 ClassPlan &c = plans[ncls];
                 ConvGeom &g = c.geom;
                 g = ConvGeom{};
                 g.N = d->N; g.Hin = d->Hin; g.Win = d->Win; g.Cin = d->Cin;
-                g.Hsub = d->Hout / 2; g.Wsub = d->Wout / 2; g.Hout = d->Hout; g.Wout = d->Wout; g.Cout = d->Cout;
-                g.s_in_y = g.s_in_x = 1; g.s_out = 2; g.off_y = a; g.off_x = b;
+                g.Hsub = Hsub; g.Wsub = Wsub; g.Hout = d->Hout; g.Wout = d->Wout; g.Cout = d->Cout;
+                g.s_in_y = g.s_in_x = 1; g.s_out_y = sh; g.s_out_x = sw; g.off_y = a; g.off_x = b;
                 g.pad_mode = 0; g.kchunks = d->Cin / 64; g.act = d->act; g.out_f32 = d->out_f32;
                 c.pack = PackGeom{};
                 c.pack.Cout = d->Cout; c.pack.Cin = d->Cin; c.pack.kh = d->kh; c.pack.kw = d->kw; c.pack.transposed = 1;
                 int t = 0, ntx = 0;
-                const int ky0 = (a + d->pad_h) & 1, kx0 = (b + d->pad_w) & 1;
-                for (int ky = ky0; ky < d->kh; ky += 2) {
+                const int ky0 = (a + d->pad_h) % sh, kx0 = (b + d->pad_w) % sw;
+                for (int ky = ky0; ky < d->kh; ky += sh) {
                     ntx = 0;
-                    for (int kx = kx0; kx < d->kw; kx += 2, ++t, ++ntx) {
+                    for (int kx = kx0; kx < d->kw; kx += sw, ++t, ++ntx) {
                         c.pack.ky[t] = (signed char)ky; c.pack.kx[t] = (signed char)kx;
                     }
                 }
-                if (t == 0) return IR2RGB_ENOSUP;
-                // iy = sy + (a + pad - ky)/2 with ky = ky0 + 2*ty  (numerator even by construction)
-                g.ntx = ntx; g.dy0 = (a + d->pad_h - ky0) / 2; g.dys = -1; g.dx0 = (b + d->pad_w - kx0) / 2; g.dxs = -1;
+                if (t == 0) return IR2RGB_ENOSUP;  // a class without taps would need a bias-only fill
+                g.ntx = ntx; g.dy0 = (a + d->pad_h - ky0) / sh; g.dys = -1; g.dx0 = (b + d->pad_w - kx0) / sw; g.dxs = -1;
                 g.ntaps = t; c.pack.ntaps = t;
                 c.w_offset = woff;
                 woff += (long)d->Cout * d->Cin * t;

@@ -29,6 +29,7 @@ import torch
 import torch.nn as nn
 from torch.nn import init
 
+from . import autograd as A
 from . import conv as C
 from . import layers as L
 
@@ -87,13 +88,14 @@ class ResnetBlock(nn.Module):
 
     def run(self, x, extra_residual=None):
         """NHWC half in/out; ``extra_residual`` is added to the block output (encoder sum)."""
-        cb, tr = self.conv_block, self.training
-        h = L.conv_stage(x, cb[1], cb[2], L.ACT_RELU, C.PAD_REFLECT, pad=1, training=tr)
-        return L.conv_stage(h, cb[5], cb[6], L.ACT_NONE, C.PAD_REFLECT, pad=1, res1=x, res2=extra_residual, training=tr)
+        cb, tr, dt = self.conv_block, self.training, x.dtype
+        h = A.conv_stage(x, cb[1], cb[2], L.ACT_RELU, C.PAD_REFLECT, dt, pad=1, training=tr)
+        return A.conv_stage(h, cb[5], cb[6], L.ACT_NONE, C.PAD_REFLECT, dt, pad=1, res1=x, res2=extra_residual,
+                            training=tr)
 
     def forward(self, x):
         dt = getattr(self, "compute_dtype", torch.bfloat16)
-        return self.run(L.to_nhwc_half(x, dt))
+        return self.run(A.to_nhwc_half(x, dt))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -112,14 +114,14 @@ def _run_sequence(seq, x, dtype, training, final_residual=None):
         m = mods[i]
         if isinstance(m, nn.ReflectionPad2d):
             conv, bn = mods[i + 1], mods[i + 2]
-            x = L.first_stage(x, conv, bn, L.ACT_RELU, C.PAD_REFLECT, dtype, training=training)
+            x = A.conv_stage(x, conv, bn, L.ACT_RELU, C.PAD_REFLECT, dtype, first=True, pad=3, training=training)
             i += 4
         elif isinstance(m, nn.ConvTranspose2d):
-            x = L.conv_stage(x, m, mods[i + 1], L.ACT_RELU, C.PAD_ZERO, transposed=True,
+            x = A.conv_stage(x, m, mods[i + 1], L.ACT_RELU, C.PAD_ZERO, dtype, transposed=True,
                              output_padding=m.output_padding[0], training=training)
             i += 3
         elif isinstance(m, nn.Conv2d):
-            x = L.conv_stage(x, m, mods[i + 1], L.ACT_RELU, C.PAD_ZERO, training=training)
+            x = A.conv_stage(x, m, mods[i + 1], L.ACT_RELU, C.PAD_ZERO, dtype, training=training)
             i += 3
         elif isinstance(m, ResnetBlock):
             x = m.run(x, final_residual if i == last_block else None)
@@ -153,15 +155,15 @@ class _CompositeBase(nn.Module):
     compute_dtype = torch.bfloat16
 
     def _heads_and_blend(self, img_feat, flow_feat, img_prev, use_raw_only, flow_mul):
-        img_raw = L.head_stage(img_feat, [self.model_final_img[1]], [1] * self.model_final_img[1].out_channels)
+        img_raw = A.head_stage(img_feat, [self.model_final_img[1]], [1] * self.model_final_img[1].out_channels)
         flow = weight = None
         if not self.no_flow:
-            fw = L.head_stage(flow_feat, [self.model_final_flow[1], self.model_final_w[1]], [0, 0, 2], mul=flow_mul)
+            fw = A.head_stage(flow_feat, [self.model_final_flow[1], self.model_final_w[1]], [0, 0, 2], mul=flow_mul)
             flow, weight = fw[:, 0:2], fw[:, 2:3]
         if use_raw_only or self.no_flow:
             img_final = img_raw
         else:
-            img_final = L.warp_blend(img_raw, img_prev.float().contiguous(), flow.contiguous(), weight.contiguous())
+            img_final = A.warp_blend(img_raw, img_prev.float(), flow, weight)
         return img_final, flow, weight, img_raw
 
     @staticmethod
@@ -250,26 +252,22 @@ class CompositeLocalGeneratorModule(_CompositeBase):
             self.model_final_flow = _seq(final_flow)
             self.model_final_w = _seq(final_w)
 
-    def _encode(self, seq, x, dt, tr, res1=None, res2=None):
+    def _encode(self, seq, x, dt, tr, res1=None):
         mods = list(seq)
-        h = L.first_stage(x, mods[1], mods[2], L.ACT_RELU, C.PAD_REFLECT, dt, training=tr)
-        desc_conv, bn = mods[4], mods[5]
-        # the stride-2 stage ends the encoder: residual adds (other encoder, coarse features) fuse here
-        desc = C.make_desc(tuple(h.shape), desc_conv.out_channels, 3, 2, 1, C.PAD_ZERO, h.dtype)
-        y, stats = C.conv2d_fwd(desc, h, L.packed_weight(desc_conv, desc), desc_conv.bias, want_stats=True)
-        scale, shift, _, _ = L.bn_finalize(stats, desc.N * desc.Hout * desc.Wout, bn, tr)
-        return L.bn_apply(y, scale, shift, L.ACT_RELU, res1, res2, out=y)
+        h = A.conv_stage(x, mods[1], mods[2], L.ACT_RELU, C.PAD_REFLECT, dt, first=True, pad=3, training=tr)
+        # the stride-2 stage ends the encoder: the other encoder's output is added in its epilogue pass
+        return A.conv_stage(h, mods[4], mods[5], L.ACT_RELU, C.PAD_ZERO, dt, res1=res1, training=tr)
 
     def forward(self, input, img_prev, mask, img_feat_coarse, flow_feat_coarse, img_fg_feat_coarse, use_raw_only):
         self._check_inputs(input, img_prev)
         dt, tr = self.compute_dtype, self.training
         seg = self._encode(self.model_down_seg, input, dt, tr)
         down_img = self._encode(self.model_down_img, img_prev, dt, tr, res1=seg)                   # (:290)
-        img_in = L.bn_apply_add(down_img, L.to_nhwc_half(img_feat_coarse, dt))                      # (:291)
+        img_in = A.add(down_img, A.to_nhwc_half(img_feat_coarse, dt))                      # (:291)
         img_feat = _run_sequence(self.model_up_img, img_in, dt, tr)
         flow_feat = None
         if not self.no_flow:
-            flow_in = L.bn_apply_add(down_img, L.to_nhwc_half(flow_feat_coarse, dt))                # (:297)
+            flow_in = A.add(down_img, A.to_nhwc_half(flow_feat_coarse, dt))                # (:297)
             flow_feat = _run_sequence(self.model_up_flow, flow_in, dt, tr)
         img_final, flow, weight, img_raw = self._heads_and_blend(img_feat, flow_feat, img_prev, use_raw_only,
                                                                  20.0 * (2 ** self.scale))
@@ -306,19 +304,15 @@ class NLayerDiscriminator(nn.Module):
 
 
 def _run_patchgan(groups, x_nchw, dtype, training):
-    """groups: list of nn.Sequential ([conv, (bn), (lrelu)]).  Returns every group's output (NHWC half,
-    the last one -- 1 channel -- as NCHW fp32)."""
-    outs = []
+    """groups: list of nn.Sequential ([conv, (bn), (lrelu)]).  Returns every group's output (channels_last
+    half; the last one -- the 1-channel logits -- as fp32)."""
     g0 = groups[0]
-    h = L.first_stage(x_nchw, g0[0], None, L.ACT_NONE, C.PAD_ZERO, dtype, fused_leaky=True, training=training)
-    outs.append(h)
+    h = A.conv_stage(x_nchw, g0[0], None, L.ACT_NONE, C.PAD_ZERO, dtype, first=True, fused_leaky=True, training=training)
+    outs = [h]
     for g in groups[1:-1]:
-        h = L.conv_stage(h, g[0], g[1], L.ACT_LEAKY, C.PAD_ZERO, training=training)
+        h = A.conv_stage(h, g[0], g[1], L.ACT_LEAKY, C.PAD_ZERO, dtype, training=training)
         outs.append(h)
-    last = groups[-1][0]
-    desc = C.make_desc(tuple(h.shape), last.out_channels, 4, 1, 2, C.PAD_ZERO, h.dtype, out_f32=True)
-    y, _ = C.conv2d_fwd(desc, h, L.packed_weight(last, desc), last.bias)
-    outs.append(y)  # [N,1,H,W]: channels_last == contiguous for a single channel
+    outs.append(A.conv_stage(h, groups[-1][0], None, L.ACT_NONE, C.PAD_ZERO, dtype, out_f32=True, training=training))
     return outs
 
 

@@ -1,0 +1,155 @@
+"""GPU unit tests of each fused stage's backward (HIP BN/activation backward, HIP data gradient via
+the adjoint convolution, fold/x-im2col adjoints, weight gradient) against torch fp32 autograd of the
+same stage evaluated on the same half-rounded inputs and weights.
+
+One stage deep, so only rounding separates the two: relative L2 <= 6e-3 (f16), 3e-2 (bf16).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-20)).item()
+
+
+def _leaf(t):
+    return t.detach().clone().requires_grad_()
+
+
+CASES = {
+    # name: (Cin, H, W, Cout, k, stride, pad, pad_mode, transposed, opad, act, use_bn, with_res)
+    "res3x3_reflect_bn_relu_res": (64, 12, 20, 64, 3, 1, 1, 1, False, 0, 1, True, True),
+    "down3x3_s2_bn_relu": (64, 16, 24, 128, 3, 2, 1, 0, False, 0, 1, True, False),
+    "up3x3T_s2_bn_relu": (128, 8, 12, 64, 3, 2, 1, 0, True, 1, 1, True, False),
+    "d4x4_s2_p2_bn_leaky_odd": (64, 17, 21, 128, 4, 2, 2, 0, False, 0, 2, True, False),
+    "d4x4_s2_p2_bn_leaky_even": (64, 16, 20, 128, 4, 2, 2, 0, False, 0, 2, True, False),
+    "d4x4_s1_p2_bn_leaky": (128, 9, 13, 256, 4, 1, 2, 0, False, 0, 2, True, False),
+}
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 6e-3), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("name", list(CASES))
+def test_stage_backward(dev, name, dtype, tol):
+    from ir2rgb_amd import autograd as A
+    from ir2rgb_amd import conv as C
+    cin, h, w, cout, k, s, p, pm, tr, op, act, use_bn, with_res = CASES[name]
+    g = torch.Generator().manual_seed(hash(name) % 1000)
+    conv = (nn.ConvTranspose2d(cin, cout, k, s, p, output_padding=op) if tr else nn.Conv2d(cin, cout, k, s, 0 if pm else p)).to(dev)
+    bn = nn.BatchNorm2d(cout).to(dev) if use_bn else None
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (1.0 / np.sqrt(cin * k * k)))
+        conv.weight.copy_(conv.weight.to(dtype).float())  # exactly representable in half
+        conv.bias.copy_(torch.randn(cout, generator=g) * 0.1)
+        if bn is not None:
+            bn.weight.copy_(1 + 0.2 * torch.randn(cout, generator=g))
+            bn.bias.copy_(0.2 * torch.randn(cout, generator=g))
+    x0 = torch.randn(2, cin, h, w, generator=g).to(dev).to(dtype)
+    xh = x0.contiguous(memory_format=torch.channels_last).requires_grad_()
+    # reference (fp32 autograd)
+    xr = _leaf(x0.float())
+    wr, br = _leaf(conv.weight), _leaf(conv.bias)
+    if tr:
+        y = F.conv_transpose2d(xr, wr, br, s, p, op)
+    elif pm:
+        y = F.conv2d(F.pad(xr, (p,) * 4, mode="reflect"), wr, br, s)
+    else:
+        y = F.conv2d(xr, wr, br, s, p)
+    gr, btr = _leaf(bn.weight), _leaf(bn.bias)
+    z = F.batch_norm(y, None, None, gr, btr, True, 0.1, 1e-5)
+    z = F.relu(z) if act == 1 else F.leaky_relu(z, 0.2)
+    res0 = torch.randn(z.shape, generator=g).to(dev).to(dtype) if with_res else None
+    rr = _leaf(res0.float()) if with_res else None
+    if with_res:
+        z = z + rr
+    proj = torch.randn(z.shape, generator=g).to(dev)
+    (z * proj).sum().backward()
+    # HIP
+    rh = res0.contiguous(memory_format=torch.channels_last).requires_grad_() if with_res else None
+    zh = A.conv_stage(xh, conv, bn, act, pm, dtype, pad=p if pm else None, transposed=tr, output_padding=op, res1=rh)
+    assert _rel(zh, z) <= tol
+    (zh.float() * proj).sum().backward()
+    errs = {"dx": _rel(xh.grad, xr.grad), "dW": _rel(conv.weight.grad, wr.grad), "dgamma": _rel(bn.weight.grad, gr.grad),
+            "dbeta": _rel(bn.bias.grad, btr.grad)}
+    if with_res:
+        errs["dres"] = _rel(rh.grad, rr.grad)
+    assert conv.bias.grad.abs().max().item() <= 1e-3 * max(1.0, wr.grad.abs().max().item())  # true value is 0
+    bad = {k2: v for k2, v in errs.items() if not v <= tol}
+    assert not bad, f"{name}: {errs}"
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 6e-3), (torch.bfloat16, 3e-2)])
+def test_first_and_last_discriminator_layers_backward(dev, dtype, tol):
+    """x-im2col first layer (Conv4x4 s2 p2 + LeakyReLU on a 6-channel NCHW fp32 image, input gradient
+    needed: the generator loss flows through it) and the 1-channel fp32 logit layer."""
+    from ir2rgb_amd import autograd as A
+    from ir2rgb_amd import conv as C
+    g = torch.Generator().manual_seed(9)
+    c0 = nn.Conv2d(6, 64, 4, 2, 2).to(dev)
+    c1 = nn.Conv2d(64, 1, 4, 1, 2).to(dev)
+    with torch.no_grad():
+        for c in (c0, c1):
+            c.weight.copy_((torch.randn(c.weight.shape, generator=g) * 0.1).to(dtype).float())
+    x0 = torch.randn(2, 6, 19, 26, generator=g).to(dev).to(dtype).float()
+    xr = _leaf(x0)
+    w0, b0, w1, b1 = _leaf(c0.weight), _leaf(c0.bias), _leaf(c1.weight), _leaf(c1.bias)
+    hr = F.leaky_relu(F.conv2d(xr, w0, b0, 2, 2), 0.2)
+    outr = F.conv2d(hr, w1, b1, 1, 2)
+    proj = torch.randn(outr.shape, generator=g).to(dev)
+    ((outr * proj).sum() + hr.sum() * 0.01).backward()
+    xh = _leaf(x0)
+    hh = A.conv_stage(xh, c0, None, 0, C.PAD_ZERO, dtype, first=True, fused_leaky=True)
+    outh = A.conv_stage(hh, c1, None, 0, C.PAD_ZERO, dtype, out_f32=True)
+    assert outh.dtype == torch.float32 and _rel(outh, outr) <= tol
+    ((outh * proj).sum() + hh.float().sum() * 0.01).backward()
+    errs = {"dx": _rel(xh.grad, xr.grad), "dW0": _rel(c0.weight.grad, w0.grad), "db0": _rel(c0.bias.grad, b0.grad),
+            "dW1": _rel(c1.weight.grad, w1.grad), "db1": _rel(c1.bias.grad, b1.grad)}
+    bad = {k: v for k, v in errs.items() if not v <= tol}
+    assert not bad, errs
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 6e-3), (torch.bfloat16, 3e-2)])
+def test_generator_first_layer_backward(dev, dtype, tol):
+    """ReflectionPad2d(3)+Conv7x7+BN+ReLU on a 9-channel image: weight / BN gradients (no input grad)."""
+    from ir2rgb_amd import autograd as A
+    from ir2rgb_amd import conv as C
+    g = torch.Generator().manual_seed(10)
+    conv, bn = nn.Conv2d(9, 64, 7).to(dev), nn.BatchNorm2d(64).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_((torch.randn(conv.weight.shape, generator=g) * 0.05).to(dtype).float())
+    x0 = torch.randn(1, 9, 20, 28, generator=g).to(dev).to(dtype).float()
+    wr, gr, btr = _leaf(conv.weight), _leaf(bn.weight), _leaf(bn.bias)
+    zr = F.relu(F.batch_norm(F.conv2d(F.pad(x0, (3,) * 4, mode="reflect"), wr, conv.bias), None, None, gr, btr, True))
+    proj = torch.randn(zr.shape, generator=g).to(dev)
+    (zr * proj).sum().backward()
+    zh = A.conv_stage(x0, conv, bn, 1, C.PAD_REFLECT, dtype, first=True, pad=3)
+    assert _rel(zh, zr) <= tol
+    (zh.float() * proj).sum().backward()
+    errs = {"dW": _rel(conv.weight.grad, wr.grad), "dgamma": _rel(bn.weight.grad, gr.grad), "dbeta": _rel(bn.bias.grad, btr.grad)}
+    bad = {k: v for k, v in errs.items() if not v <= tol}
+    assert not bad, errs
+
+
+def test_fold_reflect_and_xexpand_adjoints(dev):
+    """<A x, y> == <x, A^T y> for the two linear maps whose adjoints are hand-written."""
+    from ir2rgb_amd import autograd as A
+    from ir2rgb_amd import layers as L
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 64, 9, 11, generator=g).to(dev)
+    y = torch.randn(2, 64, 13, 15, generator=g).to(dev)
+    lhs = (F.pad(x, (2, 2, 2, 2), mode="reflect") * y).sum()
+    yt = A.fold_reflect(y.to(torch.float16).contiguous(memory_format=torch.channels_last), 2).float()
+    rhs = (x * yt).sum()
+    assert abs(lhs.item() - rhs.item()) <= 5e-3 * abs(lhs.item()) + 0.5
+    for (kw, s, p, pm) in [(7, 1, 3, 1), (4, 2, 2, 0)]:
+        img = torch.randn(2, 6, 10, 21, generator=g).to(dev)
+        e = L.xexpand(img, kw, s, p, pm, torch.float16)
+        d = torch.randn(e.shape, generator=g).to(dev).to(torch.float16).contiguous(memory_format=torch.channels_last)
+        d[:, 6 * kw:] = 0
+        lhs = (e.float() * d.float()).sum()
+        rhs = (img.half().float() * A.xexpand_bwd(d, 6, 21, kw, s, p, pm)).sum()
+        assert abs(lhs.item() - rhs.item()) <= 5e-3 * abs(lhs.item()) + 0.5, (kw, lhs.item(), rhs.item())
