@@ -1,0 +1,182 @@
+"""bench.py -- generator+discriminator training frames/sec at 512x1024 (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one window of the vid2vid inner loop on one GPU: two-scale generator
+forward (G0 composite ngf 128 @256x512 + G1 composite-local ngf 64 @512x1024), FlowNet2 reference
+flow, image discriminator (num_D 2) and two temporal discriminators, three backward passes, three
+Adam steps, RCCL all-reduce of all gradients when N > 1 (frame-parallel: every rank runs its own
+synthetic sequence; weak scaling).  Synthetic inputs and seeded random-init weights (no datasets or
+checkpoints offline), resident in HBM before the timed region.
+
+Prints ONE JSON line (rank 0).  Besides the contract keys it carries
+  roofline     -- the dominant kernel (MFMA implicit-GEMM 3x3 convolution), HIP-event timed per launch
+                  inside the timed region on the launch stream: algorithmic flops / mean duration
+                  against the 2.5 PFLOP/s dense bf16 peak (MI355X_MICROARCH.md);
+  cpu_baseline -- the plain-torch fp32 port of the same two-scale generator (oracle/networks_oracle.py)
+                  timed on the host cores, rank 0 at N=1 only, on a bounded sample;
+  extra        -- generator-forward timings incl. the north-star 512x1024 single-scale forward.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_TFLOPS = 2500.0  # dense bf16/f16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+H, W = 512, 1024
+PREROLL = 7           # windows until both temporal discriminator scales are active (steady state)
+
+
+def cpu_baseline(threads):
+    """Plain-torch fp32 port of the 2-scale generator forward on the host, one frame (bounded sample)."""
+    from ir2rgb_amd import networks as N
+    from oracle import networks_oracle as NO
+    torch.set_num_threads(threads)
+    opt = dict(gen_blocks=9, n_blocks_local=3, fg=False, no_flow=False, n_local_enhancers=1, feat_num=3)
+    torch.manual_seed(0)
+    g0 = N.build_generator_module(9, 3, 6, 128, "composite", 3, "batch", 0, **opt).train()
+    g1 = N.build_generator_module(9, 3, 6, 64, "composite-local", 3, "batch", 1, **opt).train()
+    gen = torch.Generator().manual_seed(1)
+    A = torch.tanh(torch.randn(1, 9, H, W, generator=gen))
+    P = torch.tanh(torch.randn(1, 6, H, W, generator=gen))
+    A0, P0 = torch.nn.functional.avg_pool2d(A, 2), torch.nn.functional.avg_pool2d(P, 2)
+    with torch.no_grad():
+        t0 = time.time()
+        r0 = NO.generator_forward(g0, A0, P0)
+        NO.generator_forward(g1, A, P, r0[4], r0[5])
+        dt = time.time() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": "1 frame: fp32 plain-torch port of the 2-scale generator FORWARD only (2.27 TFLOP) at 512x1024, "
+                      f"{dt:.1f} s; the GPU metric additionally runs FlowNet2, the discriminators, backward and Adam"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from ir2rgb_amd import conv as C
+    from ir2rgb_amd import vid2vid as V
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    trainer = V.Vid2VidTrainer(dev, world_size=world, seed=0, n_scales_spatial=2, compute_dtype=dtype)
+    n_windows = PREROLL + args.warmup + args.steps
+    A, B = V.synthetic_sequence(n_windows + 2, H, W, 1234 + 1000 * rank, dev)
+    torch.cuda.synchronize()
+
+    def window(i):
+        return trainer.train_window(A[:, i:i + 3], B[:, i:i + 3])
+
+    i = 0
+    for _ in range(PREROLL + args.warmup):   # untimed: steady-state sequence state + W warm-up steps
+        window(i)
+        i += 1
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    C.PROFILE = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        window(i)
+        i += 1
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof, C.PROFILE = C.PROFILE, None
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel (by total time inside the timed region)
+    best = None
+    for key, rec in prof.items():
+        tot = sum(a.elapsed_time(b) for a, b in rec["events"]) * 1e-3
+        if best is None or tot > best[1]:
+            best = (key, tot, rec)
+    key, tot, rec = best
+    n_launch = len(rec["events"])
+    avg = tot / n_launch
+    achieved = rec["flops"] / avg / 1e12
+    roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": None,
+                "kernel": "conv_igemm_kernel (MFMA implicit GEMM)",
+                "shape": dict(zip(("Cin", "Hin", "Win", "Cout", "kh", "kw", "stride", "reflect", "transposed"), key)),
+                "launches": n_launch, "avg_us": round(avg * 1e6, 1), "flops_per_launch": rec["flops"]}
+    all_conv_s = sum(sum(a.elapsed_time(b) for a, b in r["events"]) for r in prof.values()) * 1e-3
+    all_conv_flops = sum(r["flops"] * len(r["events"]) for r in prof.values())
+
+    # ---- generator-forward timings (north-star roofline config: single-scale composite ngf 128 @512x1024)
+    extra = {"mfma_conv_time_share_of_step": round(all_conv_s / elapsed / 1.0, 3),
+             "mfma_conv_aggregate_TFLOPs": round(all_conv_flops / all_conv_s / 1e12, 1)}
+    if rank == 0:
+        from ir2rgb_amd import networks as N
+        opt = dict(gen_blocks=9, n_blocks_local=3, fg=False, no_flow=False, n_local_enhancers=1, feat_num=3)
+        del trainer
+        torch.cuda.empty_cache()
+        torch.manual_seed(0)
+        g = N.build_generator_module(9, 3, 6, 128, "composite", 3, "batch", 0, **opt).to(dev).train()
+        g.compute_dtype = dtype
+        x, p = torch.tanh(torch.randn(1, 9, H, W, device=dev)), torch.tanh(torch.randn(1, 6, H, W, device=dev))
+        with torch.no_grad():
+            for _ in range(3):
+                g(x, p, None, None, None, None, False)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                g(x, p, None, None, None, None, False)
+            e1.record()
+            torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        extra["north_star_generator_forward_512x1024"] = {"ms": round(ms, 3), "TFLOPs": round(6.632 / ms * 1e3, 1),
+                                                          "frac_of_peak": round(6.632 / ms * 1e3 / PEAK_TFLOPS, 4),
+                                                          "algorithmic_TFLOP": 6.632}
+
+    frames = world * args.steps * 1  # n_frames_load = 1 frame per window per rank
+    line = {
+        "metric": "generator+discriminator frames/sec at 512x1024", "value": round(frames / elapsed, 3), "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "vid2vid training window 512x1024: 2-scale generator (composite ngf128 @256x512 + "
+                               "composite-local ngf64 @512x1024, tG=3) + FlowNet2 reference flow + image D (num_D=2) + "
+                               "2 temporal D, 3 backward passes + Adam; batch 1 frame per GPU",
+                   "parallelism": f"dp{world} (frame-parallel sequences, RCCL gradient all-reduce)"},
+        "roofline": roofline, "extra": extra,
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

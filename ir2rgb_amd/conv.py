@@ -72,6 +72,19 @@ def stats_rows(desc):
     return r
 
 
+# Optional per-launch timing (bench.py's roofline leg): when PROFILE is a dict, every convolution is
+# bracketed by HIP events on the stream it is launched on and tallied by shape.
+PROFILE = None
+
+
+def _flops(desc):
+    if desc.transposed:
+        taps = desc.kh * desc.kw / float(desc.stride_h * desc.stride_w)
+    else:
+        taps = desc.kh * desc.kw
+    return 2.0 * desc.N * desc.Hout * desc.Wout * desc.Cout * desc.Cin * taps
+
+
 def conv2d_fwd(desc, x, wpacked, bias=None, want_stats=False, out=None):
     """x: logical [N,Cin,H,W] channels_last half tensor.  Returns (y, stats_partial | None)."""
     if not is_nhwc(x) or x.dtype not in _TORCH2DT or _TORCH2DT[x.dtype] != desc.dtype:
@@ -85,8 +98,16 @@ def conv2d_fwd(desc, x, wpacked, bias=None, want_stats=False, out=None):
     stats = None
     if want_stats:
         stats = torch.empty((stats_rows(desc), 2, desc.Cout), dtype=torch.float32, device=x.device)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     with torch.cuda.device_of(x):
         rc = _lib.lib().ir2rgb_conv2d_fwd(ctypes.byref(desc), _p(x), _p(wpacked), _p(bias), _p(y), _p(stats),
                                           _lib.current_stream(x))
     _lib.check(rc, "conv2d_fwd")
+    if prof is not None:
+        e1.record()
+        key = (desc.Cin, desc.Hin, desc.Win, desc.Cout, desc.kh, desc.kw, desc.stride_h, desc.pad_mode, desc.transposed)
+        prof.setdefault(key, {"flops": _flops(desc), "events": []})["events"].append((e0, e1))
     return y, stats

@@ -86,16 +86,25 @@ bn_bwd_reduce_kernel(const uint4 *__restrict__ gz, const uint4 *__restrict__ y, 
 }
 
 // dbeta[c] = sum_blocks partial[.][0][c], dgamma[c] = sum_blocks partial[.][1][c]
-__global__ void __launch_bounds__(256)
+// (32 channels x 32 row groups per block, as bn_finalize_kernel)
+__global__ void __launch_bounds__(1024)
 bn_bwd_finalize_kernel(const float *__restrict__ partial, int nblk, int C, float *__restrict__ dgamma,
                        float *__restrict__ dbeta) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double red[2][32][33];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     double a = 0.0, b = 0.0;
-    for (int r = 0; r < nblk; ++r) {
-        a += (double)partial[((long)r * 2 + 0) * C + c];
-        b += (double)partial[((long)r * 2 + 1) * C + c];
-    }
+    if (c < C)
+        for (int r = rg; r < nblk; r += 32) {
+            a += (double)partial[((long)r * 2 + 0) * C + c];
+            b += (double)partial[((long)r * 2 + 1) * C + c];
+        }
+    red[0][rg][cl] = a;
+    red[1][rg][cl] = b;
+    __syncthreads();
+    if (rg != 0 || c >= C) return;
+    a = b = 0.0;
+    for (int r = 0; r < 32; ++r) { a += red[0][r][cl]; b += red[1][r][cl]; }
     dbeta[c] = (float)a;
     dgamma[c] = (float)b;
 }
@@ -213,7 +222,7 @@ extern "C" int ir2rgb_bn_bwd(const void *gz, const void *y, const float *scale, 
     hipStream_t s = as_stream(stream);
     bn_bwd_reduce_kernel<<<nblk, 256, 0, s>>>((const uint4 *)gz, (const uint4 *)y, scale, shift, mean, invstd, partial,
                                               npix, C, act, dtype, per);
-    bn_bwd_finalize_kernel<<<cdiv(C, 256), 256, 0, s>>>(partial, nblk, C, dgamma, dbeta);
+    bn_bwd_finalize_kernel<<<cdiv(C, 32), 1024, 0, s>>>(partial, nblk, C, dgamma, dbeta);
     long total8 = npix * (C / 8);
     bn_bwd_apply_kernel<<<stream_grid(total8, 256), 256, 0, s>>>((const uint4 *)gz, (const uint4 *)y, scale, shift, mean,
                                                                  invstd, dgamma, dbeta, (uint4 *)gy, total8, C / 8,

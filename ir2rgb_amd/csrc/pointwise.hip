@@ -21,20 +21,30 @@ static __device__ __forceinline__ uint16_t f2h(float f, int dt) {
 
 // ----------------------------------------------------------------------------------------
 // BatchNorm statistics: reduce the per-tile partials written by the conv epilogue.
-// One lane per channel (coalesced across channels); sums in double: var = E[y^2] - E[y]^2.
+// Block = 32 channels x 32 row groups (1024 threads): lanes of a wave read 32 consecutive channels
+// of two rows (coalesced 128 B each), row groups stride the partial rows, LDS combines them.
+// Sums in double: var = E[y^2] - E[y]^2.
 // ----------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 bn_finalize_kernel(const float *__restrict__ partial, int rows, int C, double count, const float *__restrict__ gamma,
                    const float *__restrict__ beta, float *__restrict__ running_mean, float *__restrict__ running_var,
                    float momentum, float eps, float *__restrict__ scale, float *__restrict__ shift,
                    float *__restrict__ mean_out, float *__restrict__ invstd_out) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double red[2][32][33];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     double s1 = 0.0, s2 = 0.0;
-    for (int r = 0; r < rows; ++r) {
-        s1 += (double)partial[((long)r * 2 + 0) * C + c];
-        s2 += (double)partial[((long)r * 2 + 1) * C + c];
-    }
+    if (c < C)
+        for (int r = rg; r < rows; r += 32) {
+            s1 += (double)partial[((long)r * 2 + 0) * C + c];
+            s2 += (double)partial[((long)r * 2 + 1) * C + c];
+        }
+    red[0][rg][cl] = s1;
+    red[1][rg][cl] = s2;
+    __syncthreads();
+    if (rg != 0 || c >= C) return;
+    s1 = s2 = 0.0;
+    for (int r = 0; r < 32; ++r) { s1 += red[0][r][cl]; s2 += red[1][r][cl]; }
     double mean = s1 / count;
     double var = s2 / count - mean * mean;
     var = var > 0.0 ? var : 0.0;
@@ -177,7 +187,7 @@ extern "C" int ir2rgb_bn_finalize(const float *stats_partial, int rows, int C, l
                                   float eps, float *scale, float *shift, float *mean_out, float *invstd_out,
                                   void *stream) {
     if (rows < 1 || C < 1 || count < 1 || !stats_partial || !scale || !shift) return IR2RGB_EINVAL;
-    bn_finalize_kernel<<<cdiv(C, 256), 256, 0, as_stream(stream)>>>(stats_partial, rows, C, (double)count, gamma, beta,
+    bn_finalize_kernel<<<cdiv(C, 32), 1024, 0, as_stream(stream)>>>(stats_partial, rows, C, (double)count, gamma, beta,
                                                                     running_mean, running_var, momentum, eps, scale,
                                                                     shift, mean_out, invstd_out);
     return ir2rgb_launch_status();

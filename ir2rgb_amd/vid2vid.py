@@ -1,0 +1,364 @@
+"""The vid2vid inner loop for IR->RGB on MI355X: generator recurrence, reference flow, discriminator
+losses, three optimizer steps -- one process per GPU, gradients all-reduced with RCCL.
+
+This is the build's own harness for SURVEY section 8 rows a8, a12, a13, a14 and section 8(e); it
+reproduces the semantics of the reference's wrappers without their single-process multi-GPU
+placement logic:
+
+    generator recurrence / pyramid      models/generator.py:99-182, :217-235; base_model.py:64-82
+    reference flow + confidence         models/flownet.py:20-57
+    image / temporal discriminator loss models/discriminator.py:90-200, :236-248, :257-283; models/loss.py:8-41,:105-113
+    loop body and optimizer order       train_vid2vid.py:54-111, :166-169
+
+Differences that do not change results: D parameters are frozen during the generator-loss pass
+(the reference computes those gradients and discards them with optimizer_d.zero_grad()); the G
+gradient all-reduce is overlapped with the D backward; sequences are frame-parallel across ranks.
+"""
+import contextlib
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from . import networks
+from .ext import warp_diff_norm
+
+DEFAULTS = dict(  # options/base_options.py, options/train_options.py
+    input_nc=3, output_nc=3, n_input_gen_frames=3, first_layer_gen_filters=128, gen_network="composite", gen_ds_layers=3,
+    gen_blocks=9, n_blocks_local=3, norm="batch", n_scales_spatial=1, fg=False, no_flow=False, n_local_enhancers=1,
+    feat_num=3, first_layer_dis_filters=64, num_D=2, n_layers_D=3, no_ganFeat=False, n_frames_D=3, n_scales_temporal=2,
+    lr=2e-4, beta1=0.5, lambda_feat=10.0, lambda_T=10.0, lambda_F=10.0, no_first_img=False, max_frames_per_gpu=1,
+    n_frames_bp=1, compute_dtype=torch.bfloat16, flownet_dtype=torch.bfloat16,
+)
+
+
+def avg_pool_pyramid(t, n_scales):
+    """[B,T,C,H,W] -> list of n_scales tensors, each AvgPool2d(3,2,1,count_include_pad=False) of the previous
+    (base_model.py:64-82)."""
+    out = [t]
+    for _ in range(1, n_scales):
+        b, tt, c, h, w = out[-1].shape
+        d = F.avg_pool2d(out[-1].reshape(-1, h, w).unsqueeze(1), 3, stride=2, padding=1, count_include_pad=False)
+        out.append(d.view(b, tt, c, h // 2, w // 2))
+    return out
+
+
+def resample(image, flow):
+    """Model.resample (base_model.py:129-136): same align_corners mismatch as the generator's warp."""
+    b, c, h, w = image.shape
+    grid = networks.get_grid(b, h, w, device=flow.device, dtype=flow.dtype)
+    fl = torch.cat([flow[:, 0:1] / ((w - 1.0) / 2.0), flow[:, 1:2] / ((h - 1.0) / 2.0)], 1)
+    return F.grid_sample(image, (grid + fl).permute(0, 2, 3, 1), mode="bilinear", padding_mode="border", align_corners=False)
+
+
+def masked_l1(a, b, mask):
+    m = mask.expand(-1, a.size(1), -1, -1)
+    return F.l1_loss(a * m, b * m)
+
+
+def gan_loss(pred, real):
+    """GANLoss with gan_mode 'ls' -> MSE against a constant target, summed over the D scales (loss.py:8-41)."""
+    total = 0
+    for scale in pred:
+        p = scale[-1].float()
+        total = total + F.mse_loss(p, torch.full_like(p, 1.0 if real else 0.0))
+    return total
+
+
+@contextlib.contextmanager
+def frozen(module):
+    ps = [p for p in module.parameters() if p.requires_grad]
+    for p in ps:
+        p.requires_grad_(False)
+    try:
+        yield
+    finally:
+        for p in ps:
+            p.requires_grad_(True)
+
+
+class FlowNet(torch.nn.Module):
+    """Frozen FlowNet2 + confidence mask (models/flownet.py)."""
+
+    def __init__(self, conv_dtype=torch.bfloat16, seed=1):
+        super().__init__()
+        from .flownet2_pytorch.models import FlowNet2
+        rng = torch.random.get_rng_state()
+        torch.manual_seed(seed)  # no checkpoint offline: the reference's own init (models.py:68-77)
+        self.flowNet = FlowNet2(conv_dtype=conv_dtype)
+        torch.random.set_rng_state(rng)
+        self.flowNet.eval()
+        for p in self.flowNet.parameters():
+            p.requires_grad_(False)
+
+    @torch.no_grad()
+    def forward(self, input_A, input_B):
+        if input_A.dim() == 5:
+            b, n, c, h, w = input_A.shape
+            flow, conf = self.compute_flow_and_conf(input_A.reshape(-1, c, h, w), input_B.reshape(-1, c, h, w))
+            return flow.view(b, n, 2, h, w), conf.view(b, n, 1, h, w)
+        return self.compute_flow_and_conf(input_A, input_B)
+
+    def compute_flow_and_conf(self, im1, im2):
+        assert im1.size(1) == 3 and im1.shape == im2.shape
+        old_h, old_w = im1.shape[2:]
+        new_h, new_w = old_h // 64 * 64, old_w // 64 * 64
+        if (old_h, old_w) != (new_h, new_w):
+            im1 = F.interpolate(im1, size=(new_h, new_w), mode="bilinear")
+            im2 = F.interpolate(im2, size=(new_h, new_w), mode="bilinear")
+        flow = self.flowNet(torch.stack([im1, im2], dim=2)).float().contiguous()
+        _, _, norm = warp_diff_norm(im1.float().contiguous(), im2.float().contiguous(), flow, want_warped=False,
+                                    want_diff=False)
+        conf = (norm * norm < 0.02).float()  # flownet.py:50,56-57: sum of squares < 0.02
+        if (old_h, old_w) != (new_h, new_w):
+            flow = F.interpolate(flow, size=(old_h, old_w), mode="bilinear") * old_h / new_h
+            conf = F.interpolate(conf, size=(old_h, old_w), mode="bilinear")
+        return flow, conf
+
+
+class FlatGrads:
+    """Parameters' .grad as views of one flat fp32 buffer: a single RCCL all-reduce per optimizer
+    (chunked so each collective is ~128 MB) with no pack / unpack copies."""
+
+    def __init__(self, params, chunk_elems=32 * 1024 * 1024):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.chunk = chunk_elems
+        self.handles = []
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce_async(self, world):
+        if world <= 1:
+            return
+        self.flat.mul_(1.0 / world)
+        for i in range(0, self.flat.numel(), self.chunk):
+            self.handles.append(dist.all_reduce(self.flat[i:i + self.chunk], op=dist.ReduceOp.SUM, async_op=True))
+
+    def wait(self):
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+
+
+class Vid2VidTrainer:
+    """One rank's models, optimizers and per-sequence state; ``train_window`` is the loop body."""
+
+    def __init__(self, device, world_size=1, seed=0, **overrides):
+        o = dict(DEFAULTS)
+        o.update(overrides)
+        self.opt, self.device, self.world = o, device, world_size
+        tG = o["n_input_gen_frames"]
+        self.n_scales, self.t_scales, self.tD = o["n_scales_spatial"], o["n_scales_temporal"], o["n_frames_D"]
+        g_in, g_prev = o["input_nc"] * tG, (tG - 1) * o["output_nc"]
+        kw = {k: o[k] for k in ("gen_blocks", "n_local_enhancers", "feat_num", "n_blocks_local", "fg", "no_flow")}
+        torch.manual_seed(seed)  # identical initial weights on every rank
+        self.netG = [networks.build_generator_module(g_in, o["output_nc"], g_prev, o["first_layer_gen_filters"],
+                                                      o["gen_network"], o["gen_ds_layers"], o["norm"], 0, **kw)]
+        for s in range(1, self.n_scales):
+            self.netG.append(networks.build_generator_module(g_in, o["output_nc"], g_prev, o["first_layer_gen_filters"] // 2 ** s,
+                                                             o["gen_network"] + "-local", o["gen_ds_layers"], o["norm"], s, **kw))
+        self.netD = networks.build_discriminator_module(o["input_nc"] + o["output_nc"], o["first_layer_dis_filters"],
+                                                        o["n_layers_D"], o["norm"], o["num_D"], not o["no_ganFeat"])
+        dt_in = o["output_nc"] * self.tD + 2 * (self.tD - 1)
+        self.netD_T = [networks.build_discriminator_module(dt_in, o["first_layer_dis_filters"], o["n_layers_D"], o["norm"],
+                                                           o["num_D"], not o["no_ganFeat"]) for _ in range(self.t_scales)]
+        for m in self.netG + [self.netD] + self.netD_T:
+            m.to(device).train()
+            m.compute_dtype = o["compute_dtype"]
+        self.flow_net = FlowNet(o["flownet_dtype"]).to(device)
+
+        g_params = [p for g in self.netG for p in g.parameters()]  # niter_fix_global = 0: all scales train
+        adam = dict(lr=o["lr"], betas=(o["beta1"], 0.999))
+        self.grads_G = FlatGrads(g_params)
+        self.grads_D = FlatGrads(self.netD.parameters())
+        self.grads_DT = [FlatGrads(d.parameters()) for d in self.netD_T]
+        self.optimizer_G = torch.optim.Adam(self.grads_G.params, **adam)
+        self.optimizer_D = torch.optim.Adam(self.grads_D.params, **adam)
+        self.optimizer_D_T = [torch.optim.Adam(g.params, **adam) for g in self.grads_DT]
+        self.reset_sequence()
+
+    # ------------------------------------------------------------------ per-sequence state
+    def reset_sequence(self):
+        self.fake_B_prev = None          # pyramid of the last tG-1 generated frames
+        self.frames_all = [None] * 4     # real_B_all, fake_B_all, flow_ref_all, conf_ref_all
+
+    # ------------------------------------------------------------------ generator (a8)
+    def generate(self, real_A_all, real_B_all):
+        """One window: [B, n_frames_load + tG - 1, C, H, W] inputs -> the reference's 7-tuple
+        (generator.py:99-123)."""
+        tG, ns = self.opt["n_input_gen_frames"], self.n_scales
+        n_load = real_A_all.size(1) - tG + 1
+        first = self.fake_B_prev is None
+        fake_pyr = avg_pool_pyramid(real_B_all[:, :tG - 1], ns) if first else self.fake_B_prev
+        A_pyr = avg_pool_pyramid(real_A_all, ns)
+        fake_raw, flows, weights = [], [], []
+        for t in range(n_load):
+            feat = flow_feat = None
+            for s in range(ns):                      # coarse to fine
+                si = ns - 1 - s
+                As = A_pyr[si]
+                b, _, _, h, w = As.shape
+                A_in = As[:, t:t + tG].reshape(b, -1, h, w)
+                prev = fake_pyr[si][:, t:t + tG - 1]
+                if t % self.opt["n_frames_bp"] == 0:
+                    prev = prev.detach()
+                out = self.netG[s](A_in, prev.reshape(b, -1, h, w), None, feat, flow_feat, None,
+                                   self.opt["no_first_img"] and first)
+                fake_B, flow, weight, raw, feat, flow_feat, _ = out
+                fake_pyr[si] = torch.cat([fake_pyr[si], fake_B.unsqueeze(1)], 1)
+                if s == ns - 1:
+                    fake_raw.append(raw.unsqueeze(1))
+                    flows.append(flow.unsqueeze(1))
+                    weights.append(weight.unsqueeze(1))
+        self.fake_B_prev = [B[:, -tG + 1:].detach() for B in fake_pyr]
+        fake_B = fake_pyr[0][:, tG - 1:]
+        return (fake_B, torch.cat(fake_raw, 1), torch.cat(flows, 1), torch.cat(weights, 1), real_A_all[:, tG - 1:],
+                real_B_all[:, tG - 2:])
+
+    # ------------------------------------------------------------------ discriminator losses (a13)
+    def _gan_and_fm(self, pred_real, pred_fake):
+        o = self.opt
+        loss_gan = gan_loss(pred_fake, True)
+        loss_fm = torch.zeros_like(loss_gan)
+        if not o["no_ganFeat"]:
+            fw, dw = 4.0 / (o["n_layers_D"] + 1), 1.0 / o["num_D"]
+            for i in range(min(len(pred_fake), o["num_D"])):
+                for j in range(len(pred_fake[i]) - 1):
+                    loss_fm = loss_fm + dw * fw * F.l1_loss(pred_fake[i][j].float(), pred_real[i][j].detach().float()) * o["lambda_feat"]
+        return loss_gan, loss_fm
+
+    def _loss_D(self, netD, real_in, fake_in):
+        """Three forwards exactly as compute_loss_D (discriminator.py:154-166)."""
+        pred_real = netD(real_in)
+        pred_fake_d = netD(fake_in.detach())
+        loss_D_real, loss_D_fake = gan_loss(pred_real, True), gan_loss(pred_fake_d, False)
+        with frozen(netD):
+            pred_fake = netD(fake_in)
+        loss_G_GAN, loss_G_FM = self._gan_and_fm(pred_real, pred_fake)
+        return loss_D_real, loss_D_fake, loss_G_GAN, loss_G_FM
+
+    def image_losses(self, real_B, fake_B, fake_B_raw, real_A, real_B_prev, fake_B_prev, flow, weight, flow_ref, conf_ref):
+        o = self.opt
+        L = {}
+        L["F_Flow"] = masked_l1(flow, flow_ref, conf_ref) * o["lambda_F"] / (2 ** (self.n_scales - 1))
+        L["F_Warp"] = masked_l1(resample(real_B_prev, flow), real_B, conf_ref) * o["lambda_T"]
+        L["W"] = masked_l1(weight, torch.zeros_like(weight), conf_ref) if o["no_first_img"] else torch.zeros((), device=flow.device)
+        L["G_VGG"] = torch.zeros((), device=flow.device)  # VGG19 weights are not available offline (no_vgg)
+        d_real, d_fake, g_gan, g_fm = self._loss_D(self.netD, torch.cat((real_A, real_B), 1), torch.cat((real_A, fake_B), 1))
+        L["G_Warp"] = masked_l1(fake_B, resample(fake_B_prev, flow_ref).detach(), conf_ref) * o["lambda_T"]
+        d_real2, d_fake2, g_gan2, g_fm2 = self._loss_D(self.netD, torch.cat((real_A, real_B), 1), torch.cat((real_A, fake_B_raw), 1))
+        L["D_real"], L["D_fake"] = d_real + d_real2, d_fake + d_fake2
+        L["G_GAN"], L["G_GAN_Feat"] = g_gan + g_gan2, g_fm + g_fm2
+        return L
+
+    def temporal_losses(self, s, real_B, fake_B, flow_ref, conf_ref):
+        """compute_loss_D_T (discriminator.py:168-184) for temporal scale s."""
+        b = real_B.size(0)
+        h, w = real_B.shape[-2:]
+        fl = (flow_ref / 20).reshape(b, -1, h, w)
+        real_in = torch.cat([real_B.reshape(b, -1, h, w), fl], 1)
+        fake_in = torch.cat([fake_B.reshape(b, -1, h, w), fl], 1)
+        d_real, d_fake, g_gan, g_fm = self._loss_D(self.netD_T[s], real_in, fake_in)
+        return {"D_T_real": d_real, "D_T_fake": d_fake, "G_T_GAN": g_gan, "G_T_GAN_Feat": g_fm}
+
+    # ------------------------------------------------------------------ temporal frame bookkeeping
+    def _skipped(self, B_all, B, t_scales):
+        """get_skipped_frames (discriminator.py:257-271)."""
+        tD = self.tD
+        B_all = torch.cat([B_all.detach(), B], 1) if B_all is not None else B
+        skipped = [None] * t_scales
+        for s in range(t_scales):
+            step = tD ** s
+            span = step * (tD - 1)
+            n_groups = min(B_all.size(1) - span, B.size(1))
+            for t in range(0, max(n_groups, 0), tD):
+                sl = B_all[:, -span - t - 1:-t:step] if t else B_all[:, -span - 1::step]
+                skipped[s] = torch.cat([skipped[s], sl.contiguous()]) if skipped[s] is not None else sl.contiguous()
+        keep = tD ** (t_scales - 1) * (tD - 1)
+        return B_all[:, -keep:] if B_all.size(1) > keep else B_all, skipped
+
+    def skipped_frames(self, real_B, fake_B, flow_ref, conf_ref):
+        """get_all_skipped_frames, dense variant (discriminator.py:219-234, :273-283)."""
+        ts = self.t_scales
+        rb_all, fb_all, fl_all, cf_all = self.frames_all
+        rb_all, rb_s = self._skipped(rb_all, real_B, ts)
+        fb_all, fb_s = self._skipped(fb_all, fake_B, ts)
+        fl_all, fl0 = self._skipped(fl_all, flow_ref, 1)
+        cf_all, cf0 = self._skipped(cf_all, conf_ref, 1)
+        fl_s, cf_s = [None] * ts, [None] * ts
+        if fl0[0] is not None:
+            fl_s[0], cf_s[0] = fl0[0][:, 1:], cf0[0][:, 1:]
+        for s in range(1, ts):
+            if rb_s[s] is not None and rb_s[s].size(1) == self.tD:
+                fl_s[s], cf_s[s] = self.flow_net(rb_s[s][:, 1:], rb_s[s][:, :-1])
+        self.frames_all = [rb_all, fb_all, fl_all, cf_all]
+        return rb_s, fb_s, fl_s, cf_s
+
+    # ------------------------------------------------------------------ the loop body (a14)
+    def train_window(self, input_A, input_B):
+        """train_vid2vid.py:54-111 for one window; returns a dict of detached scalar losses."""
+        fake_prev_last = self.fake_B_prev
+        fake_B, fake_B_raw, flow, weight, real_A, real_Bp = self.generate(input_A, input_B)
+        real_B_prev, real_B = real_Bp[:, :-1], real_Bp[:, 1:]
+        flow_ref, conf_ref = self.flow_net(real_B, real_B_prev)
+        # compute_fake_B_prev (generator.py:283-287)
+        fbp = real_B_prev[:, 0:1] if fake_prev_last is None else fake_prev_last[0][:, -1:]
+        if fake_B.size(1) > 1:
+            fbp = torch.cat([fbp, fake_B[:, :-1].detach()], 1)
+        flat = lambda t: t.reshape((-1,) + tuple(t.shape[2:]))  # noqa: E731
+        L = self.image_losses(flat(real_B), flat(fake_B), flat(fake_B_raw), flat(real_A), flat(real_B_prev), flat(fbp),
+                              flat(flow), flat(weight), flat(flow_ref), flat(conf_ref))
+        rb_s, fb_s, fl_s, cf_s = self.skipped_frames(real_B, fake_B, flow_ref, conf_ref)
+        LT = [self.temporal_losses(s, rb_s[s], fb_s[s], fl_s[s], cf_s[s]) for s in range(self.t_scales) if rb_s[s] is not None]
+        # get_losses (discriminator.py:236-248)
+        loss_D = (L["D_fake"] + L["D_real"]) * 0.5
+        loss_G = L["G_GAN"] + L["G_GAN_Feat"] + L["G_VGG"] + L["G_Warp"] + L["F_Flow"] + L["F_Warp"] + L["W"]
+        loss_D_T = []
+        for lt in LT:
+            loss_G = loss_G + lt["G_T_GAN"] + lt["G_T_GAN_Feat"]
+            loss_D_T.append((lt["D_T_fake"] + lt["D_T_real"]) * 0.5)
+        # backward passes; each optimizer's all-reduce overlaps the next backward
+        self.grads_G.zero()
+        self.grads_D.zero()
+        for gdt in self.grads_DT:
+            gdt.zero()
+        loss_G.backward()
+        self.grads_G.all_reduce_async(self.world)
+        loss_D.backward()
+        self.grads_D.all_reduce_async(self.world)
+        for s, ld in enumerate(loss_D_T):
+            ld.backward()
+            self.grads_DT[s].all_reduce_async(self.world)
+        self.grads_G.wait()
+        self.optimizer_G.step()
+        self.grads_D.wait()
+        self.optimizer_D.step()
+        for s in range(len(loss_D_T)):
+            self.grads_DT[s].wait()
+            self.optimizer_D_T[s].step()
+        out = {"G": loss_G.detach(), "D": loss_D.detach()}
+        out.update({f"D_T{s}": l.detach() for s, l in enumerate(loss_D_T)})
+        return out
+
+
+def synthetic_sequence(n_frames, h, w, seed, device, channels=3):
+    """smooth random field (Gaussian noise, 15x15 box blur, tanh) translated by a
+    per-sequence constant (dx,dy) in [-8,8]^2 px per frame.  Returns (A, B) [1, n_frames, C, H, W] in [-1,1]."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    dx, dy = [int(v) for v in torch.randint(-8, 9, (2,), generator=g)]
+    pad = 8 * n_frames + 8
+    out = []
+    for _ in range(2):
+        base = torch.randn(1, channels, h + 2 * pad, w + 2 * pad, generator=g).to(device)
+        base = torch.tanh(F.avg_pool2d(F.pad(base, (7, 7, 7, 7), mode="reflect"), 15, stride=1) * 6)
+        frames = [base[:, :, pad + t * dy:pad + t * dy + h, pad + t * dx:pad + t * dx + w] for t in range(n_frames)]
+        out.append(torch.stack(frames, 1).contiguous())
+    return out[0], out[1]
