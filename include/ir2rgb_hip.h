@@ -203,6 +203,16 @@ int ir2rgb_fold_reflect(const void *dxpad, void *dx, int N, int H, int W, int C,
 int ir2rgb_xexpand_bwd(const void *dxe, float *din, int N, int Cin, int H, int W, int Wout, int KW, int stride_w,
                        int pad_w, int pad_mode, int dtype, void *stream);
 
+/* Weight gradient of a convolution described by `d` (same descriptor as the forward call) on the
+ * matrix cores: x is the forward input [N,Hin,Win,Cin], gy the gradient w.r.t. the forward output
+ * [N,Hout,Wout,Cout] (both NHWC half, channels % 8 == 0); dw receives the gradient in the torch
+ * weight layout, fp32 ([Cout,Cin,kh,kw], or [Cin,Cout,kh,kw] when d->transposed).  `workspace`
+ * holds ir2rgb_conv2d_wgrad_workspace_elems(d) floats.  Reflection padding is honoured by the
+ * gather (no padded copy).  Replaces cuDNN's backward-filter in the reference's loss.backward(). */
+long ir2rgb_conv2d_wgrad_workspace_elems(const ir2rgb_conv_desc *d);
+int ir2rgb_conv2d_wgrad(const ir2rgb_conv_desc *d, const void *x, const void *gy, float *dw, float *workspace,
+                        void *stream);
+
 #ifdef __cplusplus
 }
 #endif

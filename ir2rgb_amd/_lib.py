@@ -49,6 +49,8 @@ PROTOTYPES = {
     "ir2rgb_bn_bwd": (c_int, [P] * 10 + [c_long, c_int, c_int, c_int, P]),
     "ir2rgb_fold_reflect": (c_int, [P, P] + [c_int] * 6 + [P]),
     "ir2rgb_xexpand_bwd": (c_int, [P, P] + [c_int] * 10 + [P]),
+    "ir2rgb_conv2d_wgrad_workspace_elems": (c_long, [_pdesc]),
+    "ir2rgb_conv2d_wgrad": (c_int, [_pdesc, P, P, P, P, P]),
 }
 
 _lib = None

@@ -8,10 +8,10 @@ short sequence of libir2rgb_hip.so calls:
     (x, gy) --wgrad--> dW
 
 Status of the pieces (see DESIGN.md "what is hand-written"): activation/BatchNorm backward, all
-data gradients, reflection fold and x-im2col adjoint are HIP.  The weight gradient, the head
-convolutions' backward and the warp-blend backward still go through torch operators on the GPU
-(``aten.convolution_backward`` / autograd recompute) -- marked INTERIM below; they compute the
-same quantities and are being replaced kernel by kernel.
+data gradients, weight gradients (MFMA, transposed LDS reads), reflection fold and x-im2col adjoint
+are HIP.  The head convolutions' backward, the warp-blend backward and the weight gradient of the
+1-channel PatchGAN logit layer still go through torch operators on the GPU -- marked INTERIM below;
+they compute the same quantities and are being replaced kernel by kernel.
 """
 import ctypes
 
@@ -132,10 +132,15 @@ def conv_dgrad(gy, conv, spec, x_shape, weight_fn=None, tag="dgrad"):
 
 
 # ---------------------------------------------------------------------------------------------
-# weight gradient -- INTERIM: torch (MIOpen) wgrad on the same half NHWC tensors
+# weight gradient: MFMA kernel (wgrad_mfma.hip); thin layers (< 8 channels on a side: PatchGAN
+# logits) still use torch's backward-filter -- INTERIM
 # ---------------------------------------------------------------------------------------------
 def conv_wgrad(x, gy, weight_shape, spec):
-    kh, kw = spec["k"]
+    cin, cout = x.shape[1], gy.shape[1]
+    if cin % 8 == 0 and cout % 8 == 0:
+        desc = C.make_desc(tuple(x.shape), cout, spec["k"], spec["stride"], spec["pad"], spec["pad_mode"], x.dtype,
+                           bool(spec["transposed"]), spec.get("output_padding", 0))
+        return C.conv2d_wgrad(desc, x, gy)
     stride, pad = list(spec["stride"]), list(spec["pad"])
     if spec["pad_mode"] == C.PAD_REFLECT and (pad[0] or pad[1]):
         x = F.pad(x, (pad[1], pad[1], pad[0], pad[0]), mode="reflect")

@@ -111,3 +111,23 @@ def conv2d_fwd(desc, x, wpacked, bias=None, want_stats=False, out=None):
         key = (desc.Cin, desc.Hin, desc.Win, desc.Cout, desc.kh, desc.kw, desc.stride_h, desc.pad_mode, desc.transposed)
         prof.setdefault(key, {"flops": _flops(desc), "events": []})["events"].append((e0, e1))
     return y, stats
+
+
+def conv2d_wgrad(desc, x, gy):
+    """Weight gradient (fp32, torch weight layout) of the convolution ``desc`` from its forward input ``x`` and the
+    gradient ``gy`` w.r.t. its output (both channels_last half)."""
+    if not (is_nhwc(x) and is_nhwc(gy)) or x.dtype != gy.dtype or _TORCH2DT.get(x.dtype) != desc.dtype:
+        raise ValueError("conv2d_wgrad: x and gy must be channels_last half tensors of the descriptor's dtype")
+    if tuple(x.shape) != (desc.N, desc.Cin, desc.Hin, desc.Win) or tuple(gy.shape) != (desc.N, desc.Cout, desc.Hout, desc.Wout):
+        raise ValueError("conv2d_wgrad: shapes do not match the descriptor")
+    lib = _lib.lib()
+    n = lib.ir2rgb_conv2d_wgrad_workspace_elems(ctypes.byref(desc))
+    if n < 0:
+        _lib.check(int(n), "conv2d_wgrad_workspace_elems")
+    ws = torch.empty(n, dtype=torch.float32, device=x.device)
+    shape = (desc.Cin, desc.Cout, desc.kh, desc.kw) if desc.transposed else (desc.Cout, desc.Cin, desc.kh, desc.kw)
+    dw = torch.empty(shape, dtype=torch.float32, device=x.device)
+    with torch.cuda.device_of(x):
+        rc = lib.ir2rgb_conv2d_wgrad(ctypes.byref(desc), _p(x), _p(gy), _p(dw), _p(ws), _lib.current_stream(x))
+    _lib.check(rc, "conv2d_wgrad")
+    return dw

@@ -1,0 +1,257 @@
+// wgrad_mfma.hip -- weight gradient of the generator / discriminator convolutions on the gfx950
+// matrix cores (what cuDNN's backward-filter does for the reference's loss.backward()).
+//
+//   D[tap][a][b] = sum_q U[q][a] * V[g(q,tap)][b]
+//
+// U [Q pixels][Ca] is the ungathered operand, V [.][Cb] the gathered one, both NHWC half:
+//   Conv2d          : U = grad wrt conv output (a = cout), V = conv input (b = cin),
+//                     g(q,tap) = (qy*stride + ky - pad, qx*stride + kx - pad)   -> dW[cout][cin][ky][kx]
+//   ConvTranspose2d : U = conv input (a = cin), V = grad wrt conv output (b = cout),
+//                     g(q,tap) = (qy*stride + ky - pad, qx*stride + kx - pad)   -> dW[cin][cout][ky][kx]
+// The contraction index (pixels) is the SLOW index of both operands in memory, so both MFMA
+// operands need a transpose: tiles are staged pixel-major into LDS with 16-byte LDS-DMA and the
+// fragments are read with ds_read_b64_tr_b16 (hardware 4x16 transpose).  LDS rows are 256 B
+// (128 channels); 32-byte channel pair P of row r is stored at pair P ^ f(r),
+// f(r) = (r & 3) | ((r >> 3) & 1) << 2, which makes the eight rows touched by one transposed read
+// (two 16-lane groups x 4 rows) hit 8 disjoint 32-byte bank windows.
+//
+// Workgroup = 256 threads (4 waves, 2x2), tile 128 (a) x 128 (b) for ONE tap and one K-split,
+// K-step = 64 pixels, two LDS stages (64 KB -> 2 workgroups per CU).  Split-K partial tiles are
+// combined with fp32 atomics into a zeroed [tap][a][b] buffer; wgrad_finish permutes it into the
+// torch weight layout.  Algorithmic flops = 2 * Q * Ca * Cb * ntaps; bound: MFMA.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct WgradGeom {
+    int N, Hq, Wq;          // pixel space of U (Q = N*Hq*Wq)
+    int Hv, Wv;             // pixel space of V
+    int Ca, Cb;
+    int stride_y, stride_x, pad_mode;
+    int nty, ntx, dy0, dx0; // tap (ty,tx): V coordinate = q*stride + (dy0+ty, dx0+tx)
+    int ksplit, ksteps;     // K-steps (64 pixels each) in total and number of splits
+    int use_atomics;
+};
+
+__device__ __attribute__((aligned(256))) uint4 g_wgrad_zero_page[16];  // 256 B of zeros
+
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+__device__ __forceinline__ void dma16(const void *src, unsigned char *dst_wave_base) {
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ int reflect1(int v, int n) {
+    v = v < 0 ? -v : v;
+    return v >= n ? 2 * n - 2 - v : v;
+}
+
+template <int DT> struct Mfma;
+template <> struct Mfma<IR2RGB_BF16> {
+    static __device__ __forceinline__ f32x4 run(s16x8 a, s16x8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mfma<IR2RGB_F16> {
+    static __device__ __forceinline__ f32x4 run(s16x8 a, s16x8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ s16x4 lds_tr(const unsigned char *p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)p);
+}
+
+template <int DT>
+__global__ void __launch_bounds__(256, 2)
+conv_wgrad_kernel(const uint16_t *__restrict__ U, const uint16_t *__restrict__ V, float *__restrict__ D,
+                  const WgradGeom g) {
+    constexpr int STAGE = 2 * 64 * 256;  // U tile + V tile, 64 pixel rows x 256 B each
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nta = (g.Ca + 127) >> 7, ntb = (g.Cb + 127) >> 7;
+    // blockIdx.x -> (split, tap, tile_a, tile_b); splits of one tile are far apart in block id
+    int bid = blockIdx.x;
+    const int tb = bid % ntb; bid /= ntb;
+    const int ta = bid % nta; bid /= nta;
+    const int tap = bid % (g.nty * g.ntx);
+    const int split = bid / (g.nty * g.ntx);
+    const int ty = tap / g.ntx, tx = tap - ty * g.ntx;
+    const int dy = g.dy0 + ty, dx = g.dx0 + tx;
+    const int a0 = ta * 128, b0 = tb * 128;
+    const int per = (g.ksteps + g.ksplit - 1) / g.ksplit;
+    const int kbeg = split * per, kend = min(g.ksteps, kbeg + per);
+    if (kbeg >= kend) return;  // workgroup-uniform
+
+    // ---------------- staging roles: 16 lanes per 256-B pixel row, 4 rows per wave instruction ----------------
+    const int slot = tid & 15, r0 = tid >> 4;                   // rows r0 + 16*i, i = 0..3
+    const int f = (r0 & 3) | (((r0 >> 3) & 1) << 2);            // same for r0 + 16*i
+    const int chunk = ((((slot >> 1) ^ f) << 1) | (slot & 1));  // source 16-B chunk held by this LDS slot
+    const bool a_ok = a0 + chunk * 8 < g.Ca, b_ok = b0 + chunk * 8 < g.Cb;
+    const uint16_t *zsrc = reinterpret_cast<const uint16_t *>(g_wgrad_zero_page) + slot * 8;
+    const uint16_t *usrc = U + a0 + chunk * 8;
+    const uint16_t *vsrc = V + b0 + chunk * 8;
+    const unsigned Q = (unsigned)g.N * g.Hq * g.Wq, HWq = (unsigned)g.Hq * g.Wq;
+    unsigned char *const wave_dst = smem + wave * 1024;  // + buf*STAGE + 4096*i (+16384 for V)
+
+    auto issue = [&](int ks, int buf) {
+        unsigned char *dst = wave_dst + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned q = (unsigned)ks * 64u + r0 + 16 * i;
+            const bool v = q < Q;
+            q = v ? q : 0u;
+            const unsigned n = q / HWq, rem = q - n * HWq;
+            const unsigned qy = rem / (unsigned)g.Wq, qx = rem - qy * g.Wq;
+            dma16((v && a_ok) ? usrc + (unsigned long)q * g.Ca : zsrc, dst + 4096 * i);
+            int iy = (int)qy * g.stride_y + dy, ix = (int)qx * g.stride_x + dx;
+            const bool inb = ((unsigned)iy < (unsigned)g.Hv) & ((unsigned)ix < (unsigned)g.Wv);
+            iy = g.pad_mode ? reflect1(iy, g.Hv) : iy;
+            ix = g.pad_mode ? reflect1(ix, g.Wv) : ix;
+            const unsigned long vp = ((unsigned long)n * g.Hv + iy) * g.Wv + ix;
+            dma16((v && b_ok && (g.pad_mode || inb)) ? vsrc + vp * g.Cb : zsrc, dst + 16384 + 4096 * i);
+        }
+    };
+
+    // ---------------- compute roles ----------------
+    const int wr = wave >> 1, wc = wave & 1;       // wave tile: rows a = wr*64.., cols b = wc*64..
+    const int grp = lane >> 4, l15 = lane & 15;
+    const int qd = l15 >> 2, pp = l15 & 3;          // transposed read: lane 4q+p -> LDS row q, channels 4p..4p+3
+    // pixel row of this lane's address within a K32 step: 8*grp + 4*h + qd  (h = 0,1)
+    // channel = tile_col0 + 16*m + 4*pp -> pair = (col0/16 + m), chunk-in-pair = pp >> 1, byte-in-chunk = (pp & 1) * 8
+    auto frag = [&](const unsigned char *tile, int col0, int kk) -> s16x8 {
+        s16x4 lo, hi;
+        {
+            const int r = kk * 32 + 8 * grp + qd;
+            const int fr = (r & 3) | (((r >> 3) & 1) << 2);
+            const int pair = (col0 >> 4) ^ fr;
+            lo = lds_tr(tile + r * 256 + pair * 32 + (pp >> 1) * 16 + (pp & 1) * 8);
+        }
+        {
+            const int r = kk * 32 + 8 * grp + 4 + qd;
+            const int fr = (r & 3) | (((r >> 3) & 1) << 2);
+            const int pair = (col0 >> 4) ^ fr;
+            hi = lds_tr(tile + r * 256 + pair * 32 + (pp >> 1) * 16 + (pp & 1) * 8);
+        }
+        return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    issue(kbeg, 0);
+    int buf = 0;
+    for (int ks = kbeg; ks < kend; ++ks) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (ks + 1 < kend) issue(ks + 1, buf ^ 1);
+        const unsigned char *tu = smem + buf * STAGE, *tv = tu + 16384;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            s16x8 a[4], b[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) a[mi] = frag(tu, wr * 64 + mi * 16, kk);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) b[ni] = frag(tv, wc * 64 + ni * 16, kk);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = Mfma<DT>::run(a[mi], b[ni], acc[mi][ni]);
+        }
+        buf ^= 1;
+    }
+
+    // ---------------- epilogue: D[tap][a][b] (fp32) ----------------
+    float *Dt = D + (long)tap * g.Ca * g.Cb;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int b = b0 + wc * 64 + ni * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a = a0 + wr * 64 + mi * 16 + grp * 4 + r;
+                if (a < g.Ca && b < g.Cb) {
+                    float *dst = Dt + (long)a * g.Cb + b;
+                    if (g.use_atomics) atomicAdd(dst, acc[mi][ni][r]);
+                    else *dst = acc[mi][ni][r];
+                }
+            }
+        }
+}
+
+// out[a][b][tap] = D[tap][a][b]   (torch weight layout [Ca][Cb][kh][kw], fp32)
+__global__ void __launch_bounds__(256)
+wgrad_finish_kernel(const float *__restrict__ D, float *__restrict__ out, int Ca, int Cb, int ntaps, long total) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % ntaps);
+        const long ab = i / ntaps;
+        out[i] = D[(long)tap * Ca * Cb + ab];
+    }
+}
+
+static int plan(const ir2rgb_conv_desc *d, WgradGeom *g) {
+    if (!d || d->N < 1 || d->Cin < 8 || d->Cout < 8 || (d->Cin % 8) || (d->Cout % 8) || d->kh < 1 || d->kw < 1 ||
+        d->stride_h < 1 || d->stride_w < 1 || d->pad_h < 0 || d->pad_w < 0)
+        return IR2RGB_EINVAL;
+    if (d->dtype != IR2RGB_BF16 && d->dtype != IR2RGB_F16) return IR2RGB_ENOSUP;
+    if (d->transposed && d->pad_mode != 0) return IR2RGB_ENOSUP;
+    *g = WgradGeom{};
+    g->N = d->N;
+    if (!d->transposed) {  // U = grad output [N,Hout,Wout,Cout], V = input [N,Hin,Win,Cin]
+        g->Hq = d->Hout; g->Wq = d->Wout; g->Hv = d->Hin; g->Wv = d->Win; g->Ca = d->Cout; g->Cb = d->Cin;
+    } else {               // U = input [N,Hin,Win,Cin], V = grad output [N,Hout,Wout,Cout]
+        g->Hq = d->Hin; g->Wq = d->Win; g->Hv = d->Hout; g->Wv = d->Wout; g->Ca = d->Cin; g->Cb = d->Cout;
+    }
+    g->stride_y = d->stride_h; g->stride_x = d->stride_w; g->pad_mode = d->pad_mode;
+    g->nty = d->kh; g->ntx = d->kw; g->dy0 = -d->pad_h; g->dx0 = -d->pad_w;
+    long Q = (long)g->N * g->Hq * g->Wq;
+    if (Q >= (1L << 31) || (long)g->N * g->Hv * g->Wv >= (1L << 31)) return IR2RGB_EINVAL;
+    g->ksteps = (int)((Q + 63) / 64);
+    long tiles = (long)d->kh * d->kw * ((g->Ca + 127) / 128) * ((g->Cb + 127) / 128);
+    int ks = (int)((768 + tiles - 1) / tiles);           // aim for ~3 workgroups per CU
+    int maxsplit = g->ksteps / 4 > 0 ? g->ksteps / 4 : 1;  // at least 4 K-steps per split
+    if (ks > maxsplit) ks = maxsplit;
+    if (ks < 1) ks = 1;
+    g->ksplit = ks;
+    g->use_atomics = ks > 1;
+    return IR2RGB_OK;
+}
+
+extern "C" long ir2rgb_conv2d_wgrad_workspace_elems(const ir2rgb_conv_desc *d) {
+    WgradGeom g;
+    int rc = plan(d, &g);
+    if (rc) return rc;
+    return (long)d->kh * d->kw * g.Ca * g.Cb;
+}
+
+extern "C" int ir2rgb_conv2d_wgrad(const ir2rgb_conv_desc *d, const void *x, const void *gy, float *dw,
+                                   float *workspace, void *stream) {
+    WgradGeom g;
+    int rc = plan(d, &g);
+    if (rc) return rc;
+    if ((((uintptr_t)x | (uintptr_t)gy) & 15) || !dw || !workspace) return IR2RGB_EALIGN;
+    hipStream_t s = as_stream(stream);
+    const int ntaps = d->kh * d->kw;
+    const long elems = (long)ntaps * g.Ca * g.Cb;
+    if (g.use_atomics) {
+        hipError_t e = hipMemsetAsync(workspace, 0, sizeof(float) * (size_t)elems, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    const uint16_t *U = (const uint16_t *)(d->transposed ? x : gy), *V = (const uint16_t *)(d->transposed ? gy : x);
+    const unsigned grid = (unsigned)((long)g.ksplit * ntaps * ((g.Ca + 127) / 128) * ((g.Cb + 127) / 128));
+    if (d->dtype == IR2RGB_BF16) conv_wgrad_kernel<IR2RGB_BF16><<<grid, 256, 0, s>>>(U, V, workspace, g);
+    else conv_wgrad_kernel<IR2RGB_F16><<<grid, 256, 0, s>>>(U, V, workspace, g);
+    wgrad_finish_kernel<<<stream_grid(elems, 256), 256, 0, s>>>(workspace, dw, g.Ca, g.Cb, ntaps, elems);
+    return ir2rgb_launch_status();
+}
