@@ -132,6 +132,11 @@ int ir2rgb_conv2d_stats_rows(const ir2rgb_conv_desc *d);
  * into the K-contiguous half-precision layout the MFMA kernel streams. */
 int ir2rgb_conv2d_pack_weight(const ir2rgb_conv_desc *d, const float *w, void *wpacked, void *stream);
 
+/* Packs the ADJOINT weights of a stride-1 Conv2d for its data-gradient convolution: `d` describes
+ * the adjoint convolution (Cin = forward Cout, Cout = forward Cin) and w is the FORWARD weight
+ * [d->Cin, d->Cout, kh, kw]; the channel swap and the tap reversal happen in the packing pass. */
+int ir2rgb_conv2d_pack_weight_adjoint(const ir2rgb_conv_desc *d, const float *w, void *wpacked, void *stream);
+
 /* y = act(conv(x) + bias); bias and stats_partial may be NULL.  x, wpacked, y 16-byte aligned. */
 int ir2rgb_conv2d_fwd(const ir2rgb_conv_desc *d, const void *x, const void *wpacked, const float *bias, void *y,
                       float *stats_partial, void *stream);

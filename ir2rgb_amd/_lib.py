@@ -37,6 +37,7 @@ PROTOTYPES = {
     "ir2rgb_conv2d_packed_weight_elems": (c_long, [_pdesc]),
     "ir2rgb_conv2d_stats_rows": (c_int, [_pdesc]),
     "ir2rgb_conv2d_pack_weight": (c_int, [_pdesc, P, P, P]),
+    "ir2rgb_conv2d_pack_weight_adjoint": (c_int, [_pdesc, P, P, P]),
     "ir2rgb_conv2d_fwd": (c_int, [_pdesc, P, P, P, P, P, P]),
     "ir2rgb_bn_finalize": (c_int, [P, c_int, c_int, c_long, P, P, P, P, c_float, c_float, P, P, P, P, P]),
     "ir2rgb_bn_apply": (c_int, [P, P, P, P, P, P, c_long, c_int, c_int, c_int, P]),

@@ -112,11 +112,11 @@ def conv_dgrad(gy, conv, spec, x_shape, weight_fn=None, tag="dgrad"):
     if sh == 1 and sw == 1:
         if spec["pad_mode"] == C.PAD_REFLECT:
             desc = C.make_desc(tuple(gy.shape), cin, (kh, kw), 1, (kh - 1, kw - 1), C.PAD_ZERO, dt)
-            wp = L.packed_weight(conv, desc, _compose(weight_fn, _flip_swap), tag=tag)
+            wp = L.packed_weight(conv, desc, weight_fn, tag=tag, adjoint=True)
             dxpad, _ = C.conv2d_fwd(desc, gy, wp)
             return fold_reflect(dxpad, ph) if ph == pw and ph > 0 else dxpad
         desc = C.make_desc(tuple(gy.shape), cin, (kh, kw), 1, (kh - 1 - ph, kw - 1 - pw), C.PAD_ZERO, dt)
-        wp = L.packed_weight(conv, desc, _compose(weight_fn, _flip_swap), tag=tag)
+        wp = L.packed_weight(conv, desc, weight_fn, tag=tag, adjoint=True)
         dx, _ = C.conv2d_fwd(desc, gy, wp)
         return dx
     # strided zero-padded convolution: adjoint = transposed convolution reading W as [in=cout][out=cin]

@@ -50,8 +50,9 @@ def empty_nhwc(n, c, h, w, dtype, device):
     return torch.empty((n, c, h, w), dtype=dtype, device=device, memory_format=torch.channels_last)
 
 
-def pack_weight(desc, weight):
-    """weight: fp32 torch layout ([Cout,Cin,kh,kw], or [Cin,Cout,kh,kw] for transposed)."""
+def pack_weight(desc, weight, adjoint=False):
+    """weight: fp32 torch layout ([Cout,Cin,kh,kw], or [Cin,Cout,kh,kw] for transposed).  adjoint=True:
+    ``desc`` is the data-gradient convolution of a stride-1 Conv2d and ``weight`` its forward weight."""
     _lib.require_device(weight, dtype=torch.float32)
     lib = _lib.lib()
     n = lib.ir2rgb_conv2d_packed_weight_elems(ctypes.byref(desc))
@@ -60,7 +61,8 @@ def pack_weight(desc, weight):
     dt = torch.bfloat16 if desc.dtype == BF16 else torch.float16
     packed = torch.empty(n, dtype=dt, device=weight.device)
     with torch.cuda.device_of(weight):
-        rc = lib.ir2rgb_conv2d_pack_weight(ctypes.byref(desc), _p(weight), _p(packed), _lib.current_stream(weight))
+        fn = lib.ir2rgb_conv2d_pack_weight_adjoint if adjoint else lib.ir2rgb_conv2d_pack_weight
+        rc = fn(ctypes.byref(desc), _p(weight), _p(packed), _lib.current_stream(weight))
     _lib.check(rc, "conv2d_pack_weight")
     return packed
 

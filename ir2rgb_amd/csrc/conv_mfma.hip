@@ -381,7 +381,8 @@ conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W
 //   ConvTranspose2d weight [Cin][Cout][kh][kw]
 // ----------------------------------------------------------------------------------------
 struct PackGeom {
-    int Cout, Cin, kh, kw, transposed;
+    int Cout, Cin, kh, kw, transposed;  // transposed: source tensor is [Cin][Cout][kh][kw]
+    int flip;                           // read tap (kh-1-ky, kw-1-kx): adjoint (data-gradient) weights
     int ntaps;
     signed char ky[IR2RGB_MAX_TAPS], kx[IR2RGB_MAX_TAPS];
 };
@@ -397,8 +398,9 @@ pack_weight_kernel(const float *__restrict__ w, uint16_t *__restrict__ wp, const
         int cc = (int)(r % kchunks);
         int co = (int)(r / kchunks);
         int ci = cc * 64 + c64;
-        long src = g.transposed ? (((long)ci * g.Cout + co) * g.kh + g.ky[tap]) * g.kw + g.kx[tap]
-                                : (((long)co * g.Cin + ci) * g.kh + g.ky[tap]) * g.kw + g.kx[tap];
+        const int ky = g.flip ? g.kh - 1 - g.ky[tap] : g.ky[tap], kx = g.flip ? g.kw - 1 - g.kx[tap] : g.kx[tap];
+        long src = g.transposed ? (((long)ci * g.Cout + co) * g.kh + ky) * g.kw + kx
+                                : (((long)co * g.Cin + ci) * g.kh + ky) * g.kw + kx;
         wp[i] = Half<DT>::cvt(w[src]);
     }
 }
@@ -522,11 +524,15 @@ extern "C" int ir2rgb_conv2d_stats_rows(const ir2rgb_conv_desc *d) {
     return rows;
 }
 
-extern "C" int ir2rgb_conv2d_pack_weight(const ir2rgb_conv_desc *d, const float *w, void *wpacked, void *stream) {
+extern "C" int ir2rgb_conv2d_pack_weight_adjoint(const ir2rgb_conv_desc *d, const float *w, void *wpacked, void *stream);
+
+static int pack_impl(const ir2rgb_conv_desc *d, const float *w, void *wpacked, void *stream, bool adjoint) {
     ClassPlan plans[4];
     int n = make_plan(d, plans);
     if (n < 0) return n;
+    if (adjoint && d->transposed) return IR2RGB_ENOSUP;
     for (int i = 0; i < n; ++i) {
+        if (adjoint) { plans[i].pack.transposed = 1; plans[i].pack.flip = 1; }
         long total = (long)d->Cout * d->Cin * plans[i].geom.ntaps;
         uint16_t *dst = reinterpret_cast<uint16_t *>(wpacked) + plans[i].w_offset;
         int grid = stream_grid(total, 256);
@@ -536,6 +542,14 @@ extern "C" int ir2rgb_conv2d_pack_weight(const ir2rgb_conv_desc *d, const float 
             pack_weight_kernel<IR2RGB_F16><<<grid, 256, 0, as_stream(stream)>>>(w, dst, plans[i].pack, total);
     }
     return ir2rgb_launch_status();
+}
+
+extern "C" int ir2rgb_conv2d_pack_weight(const ir2rgb_conv_desc *d, const float *w, void *wpacked, void *stream) {
+    return pack_impl(d, w, wpacked, stream, false);
+}
+
+extern "C" int ir2rgb_conv2d_pack_weight_adjoint(const ir2rgb_conv_desc *d, const float *w, void *wpacked, void *stream) {
+    return pack_impl(d, w, wpacked, stream, true);
 }
 
 template <int DT, int NTY, int NTX>

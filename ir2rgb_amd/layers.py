@@ -35,8 +35,8 @@ def _require_gpu(t, what):
 # ---------------------------------------------------------------------------------------------
 # packed-weight cache
 # ---------------------------------------------------------------------------------------------
-def packed_weight(mod, desc, weight=None, tag="w"):
-    """Packed half copy of ``mod.weight`` (or of ``weight``, a rearranged view of it) for ``desc``."""
+def packed_weight(mod, desc, weight=None, tag="w", adjoint=False):
+    """Packed half copy of ``mod.weight`` (or of ``weight(mod.weight)``, a rearranged form) for ``desc``."""
     src = mod.weight
     key = (tag, desc.dtype, src._version, src.data_ptr(), desc.Cin, desc.Cout, desc.kh, desc.kw, desc.transposed)
     cache = mod.__dict__.setdefault("_ir2rgb_packed", {})
@@ -44,8 +44,10 @@ def packed_weight(mod, desc, weight=None, tag="w"):
     if hit is not None and hit[0] == key:
         return hit[1]
     with torch.no_grad():
-        w = (src if weight is None else weight(src)).detach().float().contiguous()
-        packed = C.pack_weight(desc, w)
+        w = src.detach() if weight is None else weight(src.detach())
+        if w.dtype != torch.float32 or not w.is_contiguous():
+            w = w.float().contiguous()
+        packed = C.pack_weight(desc, w, adjoint=adjoint)
     cache[tag] = (key, packed)
     return packed
 

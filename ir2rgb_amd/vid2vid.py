@@ -176,7 +176,7 @@ class Vid2VidTrainer:
         self.flow_net = FlowNet(o["flownet_dtype"]).to(device)
 
         g_params = [p for g in self.netG for p in g.parameters()]  # niter_fix_global = 0: all scales train
-        adam = dict(lr=o["lr"], betas=(o["beta1"], 0.999))
+        adam = dict(lr=o["lr"], betas=(o["beta1"], 0.999), fused=True)
         self.grads_G = FlatGrads(g_params)
         self.grads_D = FlatGrads(self.netD.parameters())
         self.grads_DT = [FlatGrads(d.parameters()) for d in self.netD_T]
