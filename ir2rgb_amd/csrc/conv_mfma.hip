@@ -28,6 +28,7 @@
 // which makes every ds_read_b128 fragment read bank-conflict free.
 //
 // Algorithmic flops = 2 * pixels * Cout * ntaps * Cin; roofline bound: MFMA.
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -50,12 +51,13 @@ struct ConvGeom {
     int act;                  // 0: none, 1: LeakyReLU(0.2) after bias
     int stats_row0;           // first row of stats_partial written by this launch
     int out_f32;              // 1: Y is fp32 NHWC (head convolutions), 0: half
+    unsigned x_bytes, w_bytes; // extents of X and of this class's packed weights (buffer resources, < 2^31)
+    int variant;              // tuning switches (bit 0: waves 4-7 issue their LDS-DMA after their MFMA block)
     // taps form an nty x ntx grid: tap (ty,tx) reads input offset (dy0 + ty*dys, dx0 + tx*dxs).
     // Pure scalar arithmetic: no table load sits between the LDS-DMA issues of the K loop.
     int ntx, dy0, dys, dx0, dxs;
 };
 
-__device__ __attribute__((aligned(128))) uint4 g_zero_page[8];  // 128 B of zeros: source of padded taps
 
 template <int DT> struct Half;
 template <> struct Half<IR2RGB_BF16> {
@@ -82,9 +84,17 @@ template <> struct Half<IR2RGB_F16> {
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
-__device__ __forceinline__ void lds_dma16(const void *src, unsigned char *dst_wave_base) {
-    // 16 B per lane; LDS destination = wave-uniform base + lane * 16
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst_wave_base, 16, 0, 0);
+// Buffer-addressed LDS-DMA: 16 B per lane from (SGPR base + per-lane 32-bit byte offset + scalar byte
+// offset) to LDS at wave-uniform base + lane * 16.  The per-lane offset is range-checked against the
+// resource extent and out-of-range lanes deliver ZEROS: zero padding costs no instruction, and the
+// scalar K offset rides in an SGPR, so a K-step's staging issues no VALU address arithmetic at all.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+#define IR2RGB_OOB 0x80000000u
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void lds_dma16(rsrc_t r, unsigned voff, unsigned soff, unsigned char *dst_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr_t)dst_wave_base, 16, voff, soff, 0, 0);
 }
 
 __device__ __forceinline__ int reflect(int v, int n) {
@@ -136,12 +146,13 @@ conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W
     const int chunk = slot ^ ((r8 >> 1) & 7);  // source chunk for this thread's LDS slot (swizzle)
     const long Ktot = (long)g.kchunks * g.ntaps * 64;
 
-    const uint16_t *wsrc[WROWS];
+    const rsrc_t rw = make_rsrc(Wp, g.w_bytes), rx = make_rsrc(X, g.x_bytes);
+    unsigned woff[WROWS];  // byte offset of this thread's chunk in weight row co (K-step offset is scalar)
 #pragma unroll
     for (int i = 0; i < WROWS; ++i) {
         int co = ct * TC + r8 + 64 * i;
         co = co < g.Cout ? co : g.Cout - 1;  // clamp: rows past Cout are never stored
-        wsrc[i] = Wp + (long)co * Ktot + chunk * 8;
+        woff[i] = (unsigned)(((long)co * Ktot + chunk * 8) * 2);
     }
     int psy[PROWS], psx[PROWS];  // sub * s_in: input coordinates before the tap offset
     unsigned pbase[PROWS];       // n * Hin * Win (pixel index)
@@ -152,28 +163,22 @@ conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W
         p = v ? p : 0u;
         unsigned n = p / HW, rem = p - n * HW;
         unsigned sy = rem / (unsigned)g.Wsub;
-        // rows past the last pixel: zero padding -> parked outside the image (read the zero page);
+        // rows past the last pixel: zero padding -> parked outside the image (zero fill);
         // reflection -> pixel 0 (harmless, never stored)
         psy[i] = v ? (int)sy * g.s_in_y : (g.pad_mode ? 0 : -(1 << 20));
         psx[i] = (int)(rem - sy * g.Wsub) * g.s_in_x;
         pbase[i] = n * (unsigned)(g.Hin * g.Win);
     }
-    const uint16_t *zsrc = reinterpret_cast<const uint16_t *>(g_zero_page) + slot * 8;
-    const uint16_t *xsrc = X + chunk * 8;
     unsigned char *const wave_dst = smem + wave * 1024;  // + stage*STAGE + 8192*i (+TC*128 for pixels)
 
-    // gather offset of (row i, tap) in units of 8 elements (16 B); 0xFFFFFFFF = padded with zeros
+    // byte offset of (row i, tap) incl. this thread's chunk; IR2RGB_OOB = padded with zeros
     auto gather_off = [&](int i, int dy, int dx) -> unsigned {
         int iy = psy[i] + dy, ix = psx[i] + dx;
         const bool inb = ((unsigned)iy < (unsigned)g.Hin) & ((unsigned)ix < (unsigned)g.Win);
         iy = g.pad_mode ? reflect(iy, g.Hin) : iy;
         ix = g.pad_mode ? reflect(ix, g.Win) : ix;
-        const unsigned off = (pbase[i] + (unsigned)(iy * g.Win + ix)) * (unsigned)(g.Cin >> 3);
-        return (g.pad_mode || inb) ? off : 0xFFFFFFFFu;
-    };
-    auto dma_pixel = [&](unsigned off8, int cc, unsigned char *dst) {
-        const uint16_t *src = xsrc + (((unsigned long)off8) << 3) + cc * 64;
-        lds_dma16(off8 != 0xFFFFFFFFu ? src : zsrc, dst);
+        const unsigned off = ((pbase[i] + (unsigned)(iy * g.Win + ix)) * (unsigned)g.Cin + chunk * 8) * 2u;
+        return (g.pad_mode || inb) ? off : IR2RGB_OOB;
     };
 
     unsigned poff[STATIC_TAPS ? PROWS : 1][NT];
@@ -191,14 +196,14 @@ conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W
     int i_cc = 0, i_ty = 0, i_tx = 0, i_t = 0;
     auto issue_weights = [&](int ks, unsigned char *dst) {
 #pragma unroll
-        for (int i = 0; i < WROWS; ++i) lds_dma16(wsrc[i] + (long)ks * 64, dst + 8192 * i);
+        for (int i = 0; i < WROWS; ++i) lds_dma16(rw, woff[i], (unsigned)ks * 128u, dst + 8192 * i);
     };
     auto issue_dynamic = [&](int ks, int buf) {
         unsigned char *dst = wave_dst + buf * STAGE;
         issue_weights(ks, dst);
         const int dy = g.dy0 + i_ty * g.dys, dx = g.dx0 + i_tx * g.dxs;
 #pragma unroll
-        for (int i = 0; i < PROWS; ++i) dma_pixel(gather_off(i, dy, dx), i_cc, dst + TC * 128 + 8192 * i);
+        for (int i = 0; i < PROWS; ++i) lds_dma16(rx, gather_off(i, dy, dx), (unsigned)i_cc * 128u, dst + TC * 128 + 8192 * i);
         if (++i_tx == g.ntx) { i_tx = 0; ++i_ty; }
         if (++i_t == g.ntaps) { i_t = 0; i_ty = 0; i_tx = 0; ++i_cc; }
     };
@@ -218,6 +223,7 @@ conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = g.kchunks * g.ntaps;
+    const bool late_dma = (g.variant & 1) && wave >= 4;  // wave-uniform (SGPR)
 
     auto wait_stage = [&](int ks) {
         // stage ks has landed for THIS wave once all but the newest LOADS (stage ks+1) are done
@@ -249,7 +255,7 @@ conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W
             unsigned char *dst = wave_dst + buf * STAGE;
             issue_weights(ks, dst);
 #pragma unroll
-            for (int i = 0; i < PROWS; ++i) dma_pixel(poff[i][t], cc, dst + TC * 128 + 8192 * i);
+            for (int i = 0; i < PROWS; ++i) lds_dma16(rx, poff[i][t], (unsigned)cc * 128u, dst + TC * 128 + 8192 * i);
         };
         issue_static(0, 0, std::integral_constant<int, 0>{}, 0);
         if (nk > 1) issue_static(1, NT > 1 ? 0 : 1, std::integral_constant<int, (NT > 1 ? 1 : 0)>{}, 1);
@@ -259,13 +265,14 @@ conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W
             auto body = [&](auto tconst) {
                 constexpr int t = decltype(tconst)::value;
                 wait_stage(ks);
-                if (ks + 2 < nk) {
-                    constexpr int t2 = (t + 2) % NT;
-                    const int cc2 = cc + (t + 2) / NT;
-                    int b2 = buf + 2; b2 = b2 >= NSTAGE ? b2 - NSTAGE : b2;
-                    issue_static(ks + 2, cc2, std::integral_constant<int, t2>{}, b2);
-                }
+                constexpr int t2 = (t + 2) % NT;
+                const int cc2 = cc + (t + 2) / NT;
+                int b2 = buf + 2; b2 = b2 >= NSTAGE ? b2 - NSTAGE : b2;
+                // SIMD partners (waves w, w+4) run complementary phases: the older half stages first and
+                // multiplies second, the younger half the other way round.
+                if (!late_dma && ks + 2 < nk) issue_static(ks + 2, cc2, std::integral_constant<int, t2>{}, b2);
                 compute(buf);
+                if (late_dma && ks + 2 < nk) issue_static(ks + 2, cc2, std::integral_constant<int, t2>{}, b2);
                 ++ks;
                 buf = buf + 1 == NSTAGE ? 0 : buf + 1;
             };
@@ -278,11 +285,10 @@ conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W
         int buf = 0;
         for (int ks = 0; ks < nk; ++ks) {
             wait_stage(ks);
-            if (ks + 2 < nk) {
-                int b2 = buf + 2; b2 = b2 >= NSTAGE ? b2 - NSTAGE : b2;
-                issue_dynamic(ks + 2, b2);
-            }
+            int b2 = buf + 2; b2 = b2 >= NSTAGE ? b2 - NSTAGE : b2;
+            if (!late_dma && ks + 2 < nk) issue_dynamic(ks + 2, b2);
             compute(buf);
+            if (late_dma && ks + 2 < nk) issue_dynamic(ks + 2, b2);
             buf = buf + 1 == NSTAGE ? 0 : buf + 1;
         }
     }
@@ -415,6 +421,15 @@ struct ClassPlan {
     int npt;        // pixel tiles (TP chosen at plan time)
 };
 
+static int conv_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("IR2RGB_CONV_VARIANT");
+        v = e ? atoi(e) : 1;  // default: staggered DMA (measured +6..7 % on the large shapes)
+    }
+    return v;
+}
+
 static int tile_pixels(long P, int Cout) {
     // aim for >= 256 workgroups (one per CU); TP in {256, 128, 64}
     const long nct = (Cout + 127) / 128;
@@ -497,6 +512,10 @@ static int make_plan(const ir2rgb_conv_desc *d, ClassPlan plans[4]) {
         return IR2RGB_EINVAL;
     for (int i = 0; i < ncls; ++i) {
         ConvGeom &g = plans[i].geom;
+        g.variant = conv_variant();
+        const long xb = (long)g.N * g.Hin * g.Win * g.Cin * 2, wb = (long)g.Cout * g.Cin * g.ntaps * 2;
+        if (xb >= (1L << 31) || wb >= (1L << 31)) return IR2RGB_EINVAL;  // 32-bit buffer offsets
+        g.x_bytes = (unsigned)xb; g.w_bytes = (unsigned)wb;
         long P = (long)g.N * g.Hsub * g.Wsub;
         int tp = tile_pixels(P, g.Cout);
         plans[i].npt = (int)((P + tp - 1) / tp);
