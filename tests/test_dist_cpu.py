@@ -28,7 +28,7 @@ def _data(rank):
     return torch.randn(4, 12, generator=g), torch.randn(4, 5, generator=g)
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, outdir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from ir2rgb_amd.vid2vid import FlatGrads
@@ -43,21 +43,16 @@ def _worker(rank, world, port, out):
         fg.all_reduce_async(world)
         fg.wait()
         opt.step()
-    out.put((rank, fg.flat.clone(), torch.cat([p.detach().reshape(-1) for p in m.parameters()])))
+    torch.save((rank, fg.flat.clone(), torch.cat([p.detach().reshape(-1) for p in m.parameters()])),
+               os.path.join(outdir, f"rank{rank}.pt"))
+    dist.barrier()
     dist.destroy_process_group()
 
 
-def test_flat_gradient_allreduce_matches_global_batch():
+def test_flat_gradient_allreduce_matches_global_batch(tmp_path):
     world, port = 2, _free_port()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)  # raises with the child traceback
+    res = [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt")) for r in range(world)]
     # single-process reference: mean of the per-rank losses == loss over the global batch
     m = _model()
     opt = torch.optim.Adam(m.parameters(), lr=1e-2, betas=(0.5, 0.999))
