@@ -201,8 +201,20 @@ int ir2rgb_bn_bwd(const void *gz, const void *y, const float *scale, const float
                   const float *invstd, void *gy, float *dgamma, float *dbeta, float *partial, long npix, int C,
                   int act, int dtype, void *stream);
 
-/* Adjoint of nn.ReflectionPad2d(pad): dxpad [N,H+2p,W+2p,C] -> dx [N,H,W,C] (NHWC half). */
-int ir2rgb_fold_reflect(const void *dxpad, void *dx, int N, int H, int W, int C, int pad, int dtype, void *stream);
+/* Adjoint of nn.ReflectionPad2d: dxpad [N,H+2*pad_h,W+2*pad_w,C] -> dx [N,H,W,C] (NHWC half). */
+int ir2rgb_fold_reflect(const void *dxpad, void *dx, int N, int H, int W, int C, int pad_h, int pad_w, int dtype,
+                        void *stream);
+
+/* Backward of ir2rgb_head_finish: gout/out [N,Cout,H,W] fp32 (out = the forward result) ->
+ * dT [N,H,W,CT] half (gradient w.r.t. the separable row responses, channels >= Cout*KH zeroed)
+ * and dbias [Cout] fp32. */
+int ir2rgb_head_finish_bwd(const float *gout, const float *out, void *dT, float *dbias, int N, int H, int W, int Cout,
+                           int KH, int CT, int pad_h, unsigned acts, float mul, int dtype, void *stream);
+
+/* Backward of ir2rgb_warp_blend_fwd w.r.t. raw, flow and w (prev is a detached input on the
+ * training path, reference generator.py:153-154). */
+int ir2rgb_warp_blend_bwd(const float *gout, const float *raw, const float *prev, const float *flow, const float *w,
+                          float *graw, float *gflow, float *gw, int N, int Cp, int H, int W, void *stream);
 
 /* Adjoint of ir2rgb_xexpand: dxe [N,H,Wout,64] half -> din [N,Cin,H,W] fp32. */
 int ir2rgb_xexpand_bwd(const void *dxe, float *din, int N, int Cin, int H, int W, int Wout, int KW, int stride_w,

@@ -9,9 +9,9 @@ short sequence of libir2rgb_hip.so calls:
 
 Status of the pieces (see DESIGN.md "what is hand-written"): activation/BatchNorm backward, all
 data gradients, weight gradients (MFMA, transposed LDS reads), reflection fold and x-im2col adjoint
-are HIP.  The head convolutions' backward, the warp-blend backward and the weight gradient of the
-1-channel PatchGAN logit layer still go through torch operators on the GPU -- marked INTERIM below;
-they compute the same quantities and are being replaced kernel by kernel.
+are HIP, as are the backward of the separable head convolutions and of the warp-blend.  Only the
+weight gradient of the 1-channel PatchGAN logit layer still goes through a torch operator on the
+GPU -- marked INTERIM below.
 """
 import ctypes
 
@@ -58,12 +58,13 @@ def bn_bwd(gz, y, scale, shift, mean, invstd, act):
     return gy, dgamma, dbeta
 
 
-def fold_reflect(dxpad, pad):
+def fold_reflect(dxpad, pad_h, pad_w=None):
+    pad_w = pad_h if pad_w is None else pad_w
     n, ch, hp, wp = dxpad.shape
-    h, w = hp - 2 * pad, wp - 2 * pad
+    h, w = hp - 2 * pad_h, wp - 2 * pad_w
     dx = C.empty_nhwc(n, ch, h, w, dxpad.dtype, dxpad.device)
     with torch.cuda.device_of(dxpad):
-        rc = _lib.lib().ir2rgb_fold_reflect(_p(dxpad), _p(dx), n, h, w, ch, pad, _DT[dxpad.dtype],
+        rc = _lib.lib().ir2rgb_fold_reflect(_p(dxpad), _p(dx), n, h, w, ch, pad_h, pad_w, _DT[dxpad.dtype],
                                             _lib.current_stream(dxpad))
     _lib.check(rc, "fold_reflect")
     return dx
@@ -114,7 +115,7 @@ def conv_dgrad(gy, conv, spec, x_shape, weight_fn=None, tag="dgrad"):
             desc = C.make_desc(tuple(gy.shape), cin, (kh, kw), 1, (kh - 1, kw - 1), C.PAD_ZERO, dt)
             wp = L.packed_weight(conv, desc, weight_fn, tag=tag, adjoint=True)
             dxpad, _ = C.conv2d_fwd(desc, gy, wp)
-            return fold_reflect(dxpad, ph) if ph == pw and ph > 0 else dxpad
+            return fold_reflect(dxpad, ph, pw) if (ph or pw) else dxpad
         desc = C.make_desc(tuple(gy.shape), cin, (kh, kw), 1, (kh - 1 - ph, kw - 1 - pw), C.PAD_ZERO, dt)
         wp = L.packed_weight(conv, desc, weight_fn, tag=tag, adjoint=True)
         dx, _ = C.conv2d_fwd(desc, gy, wp)
@@ -265,36 +266,64 @@ def conv_stage(x, conv, bn, act, pad_mode, dtype, *, first=False, stride=None, p
 # ---------------------------------------------------------------------------------------------
 # heads and warp-blend: HIP forward; backward INTERIM through torch autograd recompute
 # ---------------------------------------------------------------------------------------------
+def _pad_rows(w, rows):
+    return torch.cat([w, w.new_zeros((rows - w.shape[0],) + tuple(w.shape[1:]))], 0) if w.shape[0] < rows else w
+
+
 class HeadFn(Function):
+    """Separable 7x7 head(s) on one feature map: HIP forward (1x7 MFMA pass + head_finish) and HIP
+    backward (head_finish_bwd -> adjoint 1x7 MFMA convolution + reflect fold for the feature gradient,
+    MFMA wgrad for the kernels)."""
+
     @staticmethod
     def forward(ctx, feat, acts, mul, convs, *params):
+        out = L.head_stage(feat, convs, acts, mul)
         ctx.acts, ctx.mul, ctx.convs = acts, mul, convs
-        ctx.save_for_backward(feat, *params)
-        return L.head_stage(feat, convs, acts, mul)
+        ctx.save_for_backward(feat, out)
+        return out
 
     @staticmethod
     def backward(ctx, gout):
-        feat, *params = ctx.saved_tensors
-        nconv = len(ctx.convs)
-        ws, bs = params[:nconv], params[nconv:]
-        with torch.enable_grad():
-            f = feat.detach().float().requires_grad_(ctx.needs_input_grad[0])
-            wl = [w.detach().requires_grad_() for w in ws]
-            bl = [b.detach().requires_grad_() for b in bs]
-            pre = F.conv2d(F.pad(f, (3, 3, 3, 3), mode="reflect"), torch.cat(wl, 0), torch.cat(bl, 0))
-            outs = []
-            for i, a in enumerate(ctx.acts):
-                ch = pre[:, i:i + 1]
-                outs.append(torch.tanh(ch) if a == 1 else (torch.sigmoid(ch) if a == 2 else ch * ctx.mul))
-            out = torch.cat(outs, 1)
-            wanted = ([f] if ctx.needs_input_grad[0] else []) + wl + bl
-            grads = torch.autograd.grad(out, wanted, gout.float())
-        gi = 0
+        feat, out = ctx.saved_tensors
+        convs, acts, mul = ctx.convs, ctx.acts, ctx.mul
+        kh, kw = convs[0].kernel_size
+        n, cin, h, w = feat.shape
+        cout = out.shape[1]
+        CT = 64
+        gout = gout.float().contiguous()
+        dT = C.empty_nhwc(n, CT, h, w, feat.dtype, feat.device)
+        dbias = torch.empty(cout, dtype=torch.float32, device=feat.device)
+        packed_acts = 0
+        for i, a in enumerate(acts):
+            packed_acts |= (a & 15) << (4 * i)
+        with torch.cuda.device_of(feat):
+            rc = _lib.lib().ir2rgb_head_finish_bwd(_p(gout), _p(out), _p(dT), _p(dbias), n, h, w, cout, kh, CT, kh // 2,
+                                                   packed_acts, float(mul), _DT[feat.dtype], _lib.current_stream(feat))
+        _lib.check(rc, "head_finish_bwd")
+        spec = dict(k=(1, kw), stride=(1, 1), pad=(0, kw // 2), pad_mode=C.PAD_REFLECT, transposed=False)
         gfeat = None
         if ctx.needs_input_grad[0]:
-            gfeat = grads[0].to(feat.dtype).contiguous(memory_format=torch.channels_last)
-            gi = 1
-        return (gfeat, None, None, None) + tuple(grads[gi:])
+            holder = convs[0]
+            key = ("ysplit_adj", _DT[feat.dtype]) + tuple((c.weight._version, c.weight.data_ptr()) for c in convs)
+            cache = holder.__dict__.setdefault("_ir2rgb_packed", {})
+            hit = cache.get("ysplit_adj")
+            desc = C.make_desc((n, CT, h, w), cin, (1, kw), 1, (0, kw - 1), C.PAD_ZERO, feat.dtype)
+            if hit is None or hit[0] != key:
+                with torch.no_grad():
+                    wcat = torch.cat([c.weight.detach().float() for c in convs], 0)
+                    wy = _pad_rows(L._ysplit_weight(wcat), CT).contiguous()      # [64][cin][1][kw] forward weight
+                    cache["ysplit_adj"] = (key, C.pack_weight(desc, wy, adjoint=True))
+            dpad, _ = C.conv2d_fwd(desc, dT, cache["ysplit_adj"][1])
+            gfeat = fold_reflect(dpad, 0, kw // 2)
+        wdesc = C.make_desc(tuple(feat.shape), CT, (1, kw), 1, (0, kw // 2), C.PAD_REFLECT, feat.dtype)
+        gw = C.conv2d_wgrad(wdesc, feat, dT)                                       # [64][cin][1][kw]
+        gw = gw[:cout * kh, :, 0, :].reshape(cout, kh, cin, kw).permute(0, 2, 1, 3).contiguous()   # [cout][cin][kh][kw]
+        gws, gbs, o = [], [], 0
+        for c in convs:
+            gws.append(gw[o:o + c.out_channels])
+            gbs.append(dbias[o:o + c.out_channels])
+            o += c.out_channels
+        return (gfeat, None, None, None) + tuple(gws) + tuple(gbs)
 
 
 def head_stage(feat, convs, acts, mul=1.0):
@@ -303,30 +332,37 @@ def head_stage(feat, convs, acts, mul=1.0):
 
 
 class WarpBlendFn(Function):
+    """img_final = raw*w + warp(prev, flow)*(1-w): HIP forward and HIP backward w.r.t. raw, flow, w.
+    A gradient w.r.t. prev (never needed on the training path: prev is detached, generator.py:153-154)
+    falls back to torch autograd of the same formula."""
+
     @staticmethod
     def forward(ctx, raw, prev, flow, weight):
+        raw, prev, flow, weight = raw.contiguous(), prev.contiguous(), flow.contiguous(), weight.contiguous()
         ctx.save_for_backward(raw, prev, flow, weight)
-        return L.warp_blend(raw.contiguous(), prev.contiguous(), flow.contiguous(), weight.contiguous())
+        return L.warp_blend(raw, prev, flow, weight)
 
     @staticmethod
     def backward(ctx, gout):
         raw, prev, flow, weight = ctx.saved_tensors
-        from .networks import get_grid
-        with torch.enable_grad():
-            ins = [t.detach().requires_grad_(ctx.needs_input_grad[i]) for i, t in enumerate((raw, prev, flow, weight))]
-            r, p, fl, w = ins
-            b, _, h, wd = r.shape
-            grid = get_grid(b, h, wd, device=r.device, dtype=fl.dtype)
-            fln = torch.cat([fl[:, 0:1] / ((wd - 1.0) / 2.0), fl[:, 1:2] / ((h - 1.0) / 2.0)], 1)
-            warp = F.grid_sample(p[:, -3:], (grid + fln).permute(0, 2, 3, 1), mode="bilinear", padding_mode="border",
-                                 align_corners=False)
-            out = r * w + warp * (1 - w)
-            wanted = [t for i, t in enumerate(ins) if ctx.needs_input_grad[i]]
-            grads = list(torch.autograd.grad(out, wanted, gout)) if wanted else []
-        res = []
-        for i in range(4):
-            res.append(grads.pop(0) if ctx.needs_input_grad[i] else None)
-        return tuple(res)
+        gout = gout.float().contiguous()
+        graw, gflow, gw = torch.empty_like(raw), torch.empty_like(flow), torch.empty_like(weight)
+        n, _, h, w = raw.shape
+        with torch.cuda.device_of(raw):
+            rc = _lib.lib().ir2rgb_warp_blend_bwd(_p(gout), _p(raw), _p(prev), _p(flow), _p(weight), _p(graw), _p(gflow),
+                                                  _p(gw), n, prev.shape[1], h, w, _lib.current_stream(raw))
+        _lib.check(rc, "warp_blend_bwd")
+        gprev = None
+        if ctx.needs_input_grad[1]:
+            from .networks import get_grid
+            with torch.enable_grad():
+                p = prev.detach().requires_grad_()
+                grid = get_grid(n, h, w, device=raw.device, dtype=flow.dtype)
+                fln = torch.cat([flow[:, 0:1] / ((w - 1.0) / 2.0), flow[:, 1:2] / ((h - 1.0) / 2.0)], 1)
+                warp = F.grid_sample(p[:, -3:], (grid + fln).permute(0, 2, 3, 1), mode="bilinear", padding_mode="border",
+                                     align_corners=False)
+                gprev, = torch.autograd.grad(warp, p, gout * (1 - weight))
+        return graw, gprev, gflow, gw
 
 
 def warp_blend(raw, prev, flow, weight):

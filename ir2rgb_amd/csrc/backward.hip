@@ -139,9 +139,9 @@ bn_bwd_apply_kernel(const uint4 *__restrict__ gz, const uint4 *__restrict__ y, c
 
 // dx[n][y][x][c] = sum over padded positions (py,px) that reflect onto (y,x) of dxpad[n][py][px][c]
 __global__ void __launch_bounds__(256)
-fold_reflect_kernel(const uint4 *__restrict__ dxpad, uint4 *__restrict__ dx, int H, int W, int C8, int pad,
+fold_reflect_kernel(const uint4 *__restrict__ dxpad, uint4 *__restrict__ dx, int H, int W, int C8, int pady, int padx,
                     long total8, int dt) {
-    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+    const int Hp = H + 2 * pady, Wp = W + 2 * padx;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total8; i += (long)gridDim.x * blockDim.x) {
         long r = i;
         const int c8 = (int)(r % C8); r /= C8;
@@ -150,12 +150,12 @@ fold_reflect_kernel(const uint4 *__restrict__ dxpad, uint4 *__restrict__ dx, int
         const long n = r / H;
         // candidate padded rows: y+pad (identity), pad-y (top mirror, 1<=y<=pad), pad+2H-2-y (bottom mirror)
         int ys[3], xs[3], ny = 0, nx = 0;
-        ys[ny++] = y + pad;
-        if (y >= 1 && y <= pad) ys[ny++] = pad - y;
-        if (y <= H - 2 && y >= H - 1 - pad) ys[ny++] = pad + 2 * H - 2 - y;
-        xs[nx++] = x + pad;
-        if (x >= 1 && x <= pad) xs[nx++] = pad - x;
-        if (x <= W - 2 && x >= W - 1 - pad) xs[nx++] = pad + 2 * W - 2 - x;
+        ys[ny++] = y + pady;
+        if (y >= 1 && y <= pady) ys[ny++] = pady - y;
+        if (y <= H - 2 && y >= H - 1 - pady) ys[ny++] = pady + 2 * H - 2 - y;
+        xs[nx++] = x + padx;
+        if (x >= 1 && x <= padx) xs[nx++] = padx - x;
+        if (x <= W - 2 && x >= W - 1 - padx) xs[nx++] = padx + 2 * W - 2 - x;
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int a = 0; a < ny; ++a)
             for (int b = 0; b < nx; ++b) {
@@ -230,14 +230,15 @@ extern "C" int ir2rgb_bn_bwd(const void *gz, const void *y, const float *scale, 
     return ir2rgb_launch_status();
 }
 
-extern "C" int ir2rgb_fold_reflect(const void *dxpad, void *dx, int N, int H, int W, int C, int pad, int dtype,
-                                   void *stream) {
-    if (N < 0 || H < 2 || W < 2 || C < 8 || (C % 8) || pad < 0 || pad >= H || pad >= W) return IR2RGB_EINVAL;
+extern "C" int ir2rgb_fold_reflect(const void *dxpad, void *dx, int N, int H, int W, int C, int pad_h, int pad_w,
+                                   int dtype, void *stream) {
+    if (N < 0 || H < 1 || W < 1 || C < 8 || (C % 8) || pad_h < 0 || pad_w < 0 || pad_h >= H || pad_w >= W)
+        return IR2RGB_EINVAL;
     if (dtype != IR2RGB_BF16 && dtype != IR2RGB_F16) return IR2RGB_ENOSUP;
     long total8 = (long)N * H * W * (C / 8);
     if (total8 == 0) return IR2RGB_OK;
     fold_reflect_kernel<<<stream_grid(total8, 256), 256, 0, as_stream(stream)>>>((const uint4 *)dxpad, (uint4 *)dx, H, W,
-                                                                                 C / 8, pad, total8, dtype);
+                                                                                 C / 8, pad_h, pad_w, total8, dtype);
     return ir2rgb_launch_status();
 }
 

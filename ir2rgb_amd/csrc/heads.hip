@@ -68,6 +68,107 @@ warp_blend_kernel(const float *__restrict__ raw, const float *__restrict__ prev,
     }
 }
 
+// ----------------------------------------------------------------------------------------
+// backward of head_finish: gout [N,Cout,H,W] fp32, out = saved forward output ->
+//   dpre = gout * f'(pre)  (tanh: 1-out^2, sigmoid: out(1-out), linear: mul)
+//   dT[n][y'][x][co*KH+ky] = sum_{y : refl(y+ky-pad) == y'} dpre[n][co][y][x]   (half, CT channels, rest 0)
+//   dbias_partial[block][co] = sum over the block's pixels of dpre  (reduced on the host side by a tiny sum)
+// One lane per (n, y', x): gathers the <= 3 source rows per ky (identity + two mirrors).
+// ----------------------------------------------------------------------------------------
+template <int DT>
+__global__ void __launch_bounds__(256)
+head_finish_bwd_kernel(const float *__restrict__ gout, const float *__restrict__ out, uint16_t *__restrict__ dT,
+                       float *__restrict__ dbias, int H, int W, int Cout, int KH, int CT, int pad, unsigned acts,
+                       float mul, long total) {
+    const long hw = (long)H * W;
+    float bsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (long g = blockIdx.x * (long)blockDim.x + threadIdx.x; g < total; g += (long)gridDim.x * blockDim.x) {
+        long n = g / hw, p = g - n * hw;
+        int yp = (int)(p / W), x = (int)(p - (long)yp * W);
+        uint16_t *dst = dT + g * CT;
+        for (int co = 0; co < Cout; ++co) {
+            const unsigned a = (acts >> (4 * co)) & 15u;
+            const float *go = gout + (n * Cout + co) * hw, *oo = out + (n * Cout + co) * hw;
+            auto dpre = [&](int y) -> float {
+                float o = oo[(long)y * W + x], gg = go[(long)y * W + x];
+                return a == 1 ? gg * (1.f - o * o) : (a == 2 ? gg * o * (1.f - o) : gg * mul);
+            };
+            bsum[co] += dpre(yp);
+            for (int ky = 0; ky < KH; ++ky) {
+                // rows y with refl(y + ky - pad) == yp:  t = y + ky - pad in {yp, -yp, 2H-2-yp}
+                float acc = 0.f;
+                int t = yp;
+                int y = t - ky + pad;
+                if (y >= 0 && y < H) acc += dpre(y);
+                if (yp >= 1) { t = -yp; y = t - ky + pad; if (y >= 0 && y < H && t >= -pad) acc += dpre(y); }
+                if (yp <= H - 2) { t = 2 * H - 2 - yp; y = t - ky + pad; if (y >= 0 && y < H && t <= H - 1 + pad) acc += dpre(y); }
+                float v = acc;
+                uint16_t h;
+                if (DT == IR2RGB_BF16) { __bf16 b = (__bf16)v; h = __builtin_bit_cast(uint16_t, b); }
+                else { _Float16 b = (_Float16)v; h = __builtin_bit_cast(uint16_t, b); }
+                dst[co * KH + ky] = h;
+            }
+        }
+        for (int c = Cout * KH; c < CT; ++c) dst[c] = 0;
+    }
+    // block reduction of the bias sums -> one atomic per block per channel
+    __shared__ float red[8][256];
+    for (int co = 0; co < Cout; ++co) red[co][threadIdx.x] = bsum[co];
+    __syncthreads();
+    if (threadIdx.x < Cout) {
+        float s = 0.f;
+        for (int i = 0; i < 256; ++i) s += red[threadIdx.x][i];
+        atomicAdd(dbias + threadIdx.x, s);
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// backward of warp_blend w.r.t. raw, weight and flow (prev is a detached input on the training path)
+//   out = raw*w + warp*(1-w);  warp = bilinear(prev, ix(flow_x), iy(flow_y)) with border clamping
+// ----------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+warp_blend_bwd_kernel(const float *__restrict__ gout, const float *__restrict__ raw, const float *__restrict__ prev,
+                      const float *__restrict__ flow, const float *__restrict__ wgt, float *__restrict__ graw,
+                      float *__restrict__ gflow, float *__restrict__ gw, int Cp, int H, int W, long total) {
+    const long hw = (long)H * W;
+    for (long g = blockIdx.x * (long)blockDim.x + threadIdx.x; g < total; g += (long)gridDim.x * blockDim.x) {
+        long n = g / hw, p = g - n * hw;
+        int y = (int)(p / W), x = (int)(p - (long)y * W);
+        float gx = lin_m1_p1(x, W) + flow[(n * 2 + 0) * hw + p] / ((W - 1.0f) / 2.0f);
+        float gy = lin_m1_p1(y, H) + flow[(n * 2 + 1) * hw + p] / ((H - 1.0f) / 2.0f);
+        float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f;
+        float iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+        // d(ix)/d(flow_x) = W/(W-1) inside the image, 0 where the border clamp is active (torch clip_coordinates_set_grad)
+        float dix = (ix > 0.f && ix < (float)(W - 1)) ? (float)W / (W - 1.0f) : 0.f;
+        float diy = (iy > 0.f && iy < (float)(H - 1)) ? (float)H / (H - 1.0f) : 0.f;
+        ix = fminf(fmaxf(ix, 0.f), (float)(W - 1));
+        iy = fminf(fmaxf(iy, 0.f), (float)(H - 1));
+        float fx = floorf(ix), fy = floorf(iy);
+        float tx = ix - fx, ty = iy - fy;
+        int x0 = (int)fx, y0 = (int)fy;
+        bool x1ok = x0 + 1 <= W - 1, y1ok = y0 + 1 <= H - 1;
+        int x1 = x1ok ? x0 + 1 : x0, y1 = y1ok ? y0 + 1 : y0;
+        float m = wgt[n * hw + p];
+        float gwsum = 0.f, gfx = 0.f, gfy = 0.f;
+        for (int c = 0; c < 3; ++c) {
+            const float *pl = prev + (n * Cp + (Cp - 3 + c)) * hw;
+            float p00 = pl[(long)y0 * W + x0], p01 = x1ok ? pl[(long)y0 * W + x1] : 0.f;
+            float p10 = y1ok ? pl[(long)y1 * W + x0] : 0.f, p11 = (x1ok && y1ok) ? pl[(long)y1 * W + x1] : 0.f;
+            float warp = p00 * (1.f - tx) * (1.f - ty) + p01 * tx * (1.f - ty) + p10 * (1.f - tx) * ty + p11 * tx * ty;
+            float go = gout[(n * 3 + c) * hw + p];
+            float r = raw[(n * 3 + c) * hw + p];
+            graw[(n * 3 + c) * hw + p] = go * m;
+            gwsum += go * (r - warp);
+            float gwarp = go * (1.f - m);
+            gfx += gwarp * ((p01 - p00) * (1.f - ty) + (p11 - p10) * ty);
+            gfy += gwarp * ((p10 - p00) * (1.f - tx) + (p11 - p01) * tx);
+        }
+        gw[n * hw + p] = gwsum;
+        gflow[(n * 2 + 0) * hw + p] = gfx * dix;  // d(ix)/d(flow_x) = (W/2) * 2/(W-1)
+        gflow[(n * 2 + 1) * hw + p] = gfy * diy;
+    }
+}
+
 extern "C" int ir2rgb_head_finish(const float *T, const float *bias, float *out, int N, int H, int W, int Cout, int KH,
                                   int CT, int pad_h, unsigned acts, float mul, void *stream) {
     if (N < 0 || H < 1 || W < 1 || Cout < 1 || Cout > 8 || KH < 1 || CT < Cout * KH || pad_h < 0 || pad_h >= H)
@@ -86,5 +187,35 @@ extern "C" int ir2rgb_warp_blend_fwd(const float *raw, const float *prev, const 
     if (total == 0) return IR2RGB_OK;
     warp_blend_kernel<<<stream_grid(total, 256), 256, 0, as_stream(stream)>>>(raw, prev, flow, w, out, warp_out, Cp, H, W,
                                                                               total);
+    return ir2rgb_launch_status();
+}
+
+extern "C" int ir2rgb_head_finish_bwd(const float *gout, const float *out, void *dT, float *dbias, int N, int H, int W,
+                                      int Cout, int KH, int CT, int pad_h, unsigned acts, float mul, int dtype,
+                                      void *stream) {
+    if (N < 0 || H < 2 || W < 1 || Cout < 1 || Cout > 8 || KH < 1 || CT < Cout * KH || pad_h < 0 || pad_h >= H)
+        return IR2RGB_EINVAL;
+    if (dtype != IR2RGB_BF16 && dtype != IR2RGB_F16) return IR2RGB_ENOSUP;
+    long total = (long)N * H * W;
+    hipStream_t s = as_stream(stream);
+    hipError_t e = hipMemsetAsync(dbias, 0, sizeof(float) * Cout, s);
+    if (e != hipSuccess) return (int)e;
+    if (total == 0) return IR2RGB_OK;
+    int grid = stream_grid(total, 256);
+    if (dtype == IR2RGB_BF16)
+        head_finish_bwd_kernel<IR2RGB_BF16><<<grid, 256, 0, s>>>(gout, out, (uint16_t *)dT, dbias, H, W, Cout, KH, CT, pad_h, acts, mul, total);
+    else
+        head_finish_bwd_kernel<IR2RGB_F16><<<grid, 256, 0, s>>>(gout, out, (uint16_t *)dT, dbias, H, W, Cout, KH, CT, pad_h, acts, mul, total);
+    return ir2rgb_launch_status();
+}
+
+extern "C" int ir2rgb_warp_blend_bwd(const float *gout, const float *raw, const float *prev, const float *flow,
+                                     const float *w, float *graw, float *gflow, float *gw, int N, int Cp, int H, int W,
+                                     void *stream) {
+    if (N < 0 || Cp < 3 || H < 2 || W < 2) return IR2RGB_EINVAL;
+    long total = (long)N * H * W;
+    if (total == 0) return IR2RGB_OK;
+    warp_blend_bwd_kernel<<<stream_grid(total, 256), 256, 0, as_stream(stream)>>>(gout, raw, prev, flow, w, graw, gflow, gw,
+                                                                                  Cp, H, W, total);
     return ir2rgb_launch_status();
 }

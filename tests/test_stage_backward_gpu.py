@@ -190,3 +190,51 @@ def test_wgrad_kernel_vs_torch(dev, dtype, case):
     (y * gy.float()).sum().backward()
     assert dw.shape == wr.grad.shape
     assert _rel(dw, wr.grad) <= 2e-3, _rel(dw, wr.grad)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 1e-2), (torch.bfloat16, 4e-2)])
+def test_head_and_warp_blend_backward(dev, dtype, tol):
+    """Separable 7x7 heads (tanh image head; flow*20 + sigmoid weight heads sharing one feature map) and
+    the warp-blend, forward and backward, vs torch fp32 autograd of the reference formulas."""
+    from ir2rgb_amd import autograd as A
+    from ir2rgb_amd.networks import get_grid
+    g = torch.Generator().manual_seed(31)
+    n, c, h, w = 1, 64, 24, 40
+    feat0 = torch.randn(n, c, h, w, generator=g).to(dev).to(dtype)
+    conv_f, conv_w = nn.Conv2d(c, 2, 7).to(dev), nn.Conv2d(c, 1, 7).to(dev)
+    conv_i = nn.Conv2d(c, 3, 7).to(dev)
+    with torch.no_grad():
+        for cv, sc in ((conv_f, 0.002), (conv_w, 0.02), (conv_i, 0.02)):
+            cv.weight.copy_((torch.randn(cv.weight.shape, generator=g) * sc).to(dtype).float())
+    prev = torch.rand(n, 6, h, w, generator=g).to(dev)
+    proj = torch.randn(n, 3, h, w, generator=g).to(dev)
+
+    def ref():
+        f = _leaf(feat0.float())
+        ws = [_leaf(cv.weight) for cv in (conv_f, conv_w, conv_i)]
+        bs = [_leaf(cv.bias) for cv in (conv_f, conv_w, conv_i)]
+        fp = F.pad(f, (3,) * 4, mode="reflect")
+        flow = F.conv2d(fp, ws[0], bs[0]) * 20
+        wgt = torch.sigmoid(F.conv2d(fp, ws[1], bs[1]))
+        raw = torch.tanh(F.conv2d(fp, ws[2], bs[2]))
+        grid = get_grid(n, h, w, device=dev)
+        fl = torch.cat([flow[:, 0:1] / ((w - 1.0) / 2.0), flow[:, 1:2] / ((h - 1.0) / 2.0)], 1)
+        warp = F.grid_sample(prev[:, -3:], (grid + fl).permute(0, 2, 3, 1), mode="bilinear", padding_mode="border", align_corners=False)
+        out = raw * wgt + warp * (1 - wgt)
+        ((out * proj).sum() + flow.pow(2).mean() + wgt.sum() * 0.1).backward()
+        return out, f.grad, [x.grad for x in ws], [x.grad for x in bs]
+
+    out_r, gf_r, gw_r, gb_r = ref()
+    fh = feat0.contiguous(memory_format=torch.channels_last).requires_grad_()
+    fw = A.head_stage(fh, [conv_f, conv_w], [0, 0, 2], mul=20.0)
+    raw = A.head_stage(fh, [conv_i], [1, 1, 1])
+    flow, wgt = fw[:, 0:2], fw[:, 2:3]
+    out_h = A.warp_blend(raw, prev, flow, wgt)
+    assert _rel(out_h, out_r) <= tol
+    ((out_h * proj).sum() + flow.pow(2).mean() + wgt.sum() * 0.1).backward()
+    errs = {"dfeat": _rel(fh.grad, gf_r)}
+    for name, cv, gw, gb in zip(("flow", "w", "img"), (conv_f, conv_w, conv_i), gw_r, gb_r):
+        errs[f"dW_{name}"] = _rel(cv.weight.grad, gw)
+        errs[f"db_{name}"] = _rel(cv.bias.grad, gb)
+    bad = {k: v for k, v in errs.items() if not v <= tol}
+    assert not bad, errs
