@@ -188,8 +188,9 @@ int ir2rgb_warp_blend_fwd(const float *raw, const float *prev, const float *flow
  * what torch.autograd + cuDNN do for the reference's loss.backward() (train_vid2vid.py:166-169).
  * ------------------------------------------------------------------------------------------ */
 
-/* Rows of the `partial` scratch ([rows][2][C] fp32) needed by ir2rgb_bn_bwd (< 0: error;
- * C must be a power of two in [64, 2048]). */
+/* Rows R of the scratch needed by ir2rgb_bn_bwd: `partial` must hold (R*2 + 3)*C floats
+ * ([R][2][C] block partial sums followed by three coefficient vectors).  < 0: error; C must be a
+ * power of two in [64, 2048]. */
 int ir2rgb_bn_bwd_blocks(long npix, int C);
 
 /* Backward of activation + training-mode BatchNorm2d on NHWC half tensors:

@@ -9,9 +9,8 @@ short sequence of libir2rgb_hip.so calls:
 
 Status of the pieces (see DESIGN.md "what is hand-written"): activation/BatchNorm backward, all
 data gradients, weight gradients (MFMA, transposed LDS reads), reflection fold and x-im2col adjoint
-are HIP, as are the backward of the separable head convolutions and of the warp-blend.  Only the
-weight gradient of the 1-channel PatchGAN logit layer still goes through a torch operator on the
-GPU -- marked INTERIM below.
+are HIP, as are the backward of the separable head convolutions and of the warp-blend.  No torch
+convolution is left on the generator / discriminator path, forward or backward.
 """
 import ctypes
 
@@ -47,7 +46,7 @@ def bn_bwd(gz, y, scale, shift, mean, invstd, act):
     if nblk < 0:
         _lib.check(nblk, "bn_bwd_blocks")
     dev = y.device
-    partial = torch.empty((nblk, 2, ch), dtype=torch.float32, device=dev)
+    partial = torch.empty((nblk * 2 + 3) * ch, dtype=torch.float32, device=dev)
     dgamma = torch.empty(ch, dtype=torch.float32, device=dev)
     dbeta = torch.empty(ch, dtype=torch.float32, device=dev)
     gy = torch.empty_like(y, memory_format=torch.channels_last)
@@ -133,24 +132,25 @@ def conv_dgrad(gy, conv, spec, x_shape, weight_fn=None, tag="dgrad"):
 
 
 # ---------------------------------------------------------------------------------------------
-# weight gradient: MFMA kernel (wgrad_mfma.hip); thin layers (< 8 channels on a side: PatchGAN
-# logits) still use torch's backward-filter -- INTERIM
+# weight gradient: MFMA kernel (wgrad_mfma.hip).  Thin gradients (the 1-channel PatchGAN logits)
+# are zero-padded to 8 channels so they take the same kernel.
 # ---------------------------------------------------------------------------------------------
 def conv_wgrad(x, gy, weight_shape, spec):
     cin, cout = x.shape[1], gy.shape[1]
-    if cin % 8 == 0 and cout % 8 == 0:
-        desc = C.make_desc(tuple(x.shape), cout, spec["k"], spec["stride"], spec["pad"], spec["pad_mode"], x.dtype,
-                           bool(spec["transposed"]), spec.get("output_padding", 0))
-        return C.conv2d_wgrad(desc, x, gy)
-    stride, pad = list(spec["stride"]), list(spec["pad"])
-    if spec["pad_mode"] == C.PAD_REFLECT and (pad[0] or pad[1]):
-        x = F.pad(x, (pad[1], pad[1], pad[0], pad[0]), mode="reflect")
-        pad = [0, 0]
-    wlike = torch.empty(weight_shape, dtype=x.dtype, device=x.device).contiguous(memory_format=torch.channels_last)
-    opad = [spec.get("output_padding", 0)] * 2
-    gw = torch.ops.aten.convolution_backward(gy, x, wlike, None, stride, pad, [1, 1], bool(spec["transposed"]),
-                                             opad if spec["transposed"] else [0, 0], 1, [False, True, False])[1]
-    return gw.float()
+    if cin % 8:
+        raise NotImplementedError("weight gradient needs an input channel count that is a multiple of 8")
+    if cout % 8:
+        if spec["transposed"]:
+            raise NotImplementedError("thin transposed convolutions do not occur on this path")
+        pad = (-cout) % 8
+        gp = torch.zeros((gy.shape[0], cout + pad, gy.shape[2], gy.shape[3]), dtype=gy.dtype, device=gy.device).contiguous(
+            memory_format=torch.channels_last)
+        gp[:, :cout] = gy
+        desc = C.make_desc(tuple(x.shape), cout + pad, spec["k"], spec["stride"], spec["pad"], spec["pad_mode"], x.dtype)
+        return C.conv2d_wgrad(desc, x, gp)[:cout].contiguous()
+    desc = C.make_desc(tuple(x.shape), cout, spec["k"], spec["stride"], spec["pad"], spec["pad_mode"], x.dtype,
+                       bool(spec["transposed"]), spec.get("output_padding", 0))
+    return C.conv2d_wgrad(desc, x, gy)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -212,7 +212,7 @@ class ConvStageFn(Function):
             gz = _as_half_nhwc(gz, hdt)
             gy, dgamma, dbeta = bn_bwd(gz, y, scale, shift, mean, invstd, spec["act"])
             gy_thin = gy
-            dbias = torch.zeros(y.shape[1], dtype=torch.float32, device=y.device)  # BN removes the mean: exactly 0
+            dbias = None  # BatchNorm removes the per-channel mean: the bias gradient is exactly 0
         else:
             gz = _as_half_nhwc(gz, hdt)
             act = 2 if spec["fused_leaky"] else 0  # LeakyReLU keeps the sign: mask from the stored output

@@ -86,10 +86,13 @@ bn_bwd_reduce_kernel(const uint4 *__restrict__ gz, const uint4 *__restrict__ y, 
 }
 
 // dbeta[c] = sum_blocks partial[.][0][c], dgamma[c] = sum_blocks partial[.][1][c]
-// (32 channels x 32 row groups per block, as bn_finalize_kernel)
+// (32 channels x 32 row groups per block, as bn_finalize_kernel).  Also emits the three coefficient
+// vectors of the apply pass:  gy = cA*g' + cB*y + cC  with
+//   cA = scale, cB = -scale*invstd*dgamma/n, cC = scale*(invstd*mean*dgamma/n - dbeta/n).
 __global__ void __launch_bounds__(1024)
-bn_bwd_finalize_kernel(const float *__restrict__ partial, int nblk, int C, float *__restrict__ dgamma,
-                       float *__restrict__ dbeta) {
+bn_bwd_finalize_kernel(const float *__restrict__ partial, int nblk, int C, const float *__restrict__ scale,
+                       const float *__restrict__ mean, const float *__restrict__ invstd, float inv_n,
+                       float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ coef) {
     __shared__ double red[2][32][33];
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
@@ -107,31 +110,47 @@ bn_bwd_finalize_kernel(const float *__restrict__ partial, int nblk, int C, float
     for (int r = 0; r < 32; ++r) { a += red[0][r][cl]; b += red[1][r][cl]; }
     dbeta[c] = (float)a;
     dgamma[c] = (float)b;
+    if (scale) {
+        const float sc = scale[c], is = invstd[c], mu = mean[c];
+        const float dg = (float)b * inv_n, db = (float)a * inv_n;
+        coef[c] = sc;
+        coef[C + c] = -sc * is * dg;
+        coef[2 * C + c] = sc * (is * mu * dg - db);
+    }
 }
 
-// gy = scale * (g' - dbeta/n - yhat * dgamma/n)     (BatchNorm stage)
-// gy = g'                                            (scale == nullptr: activation only)
+// gy = cA*g' + cB*y + cC, g' = gz * act'(y*scale + shift)   (BatchNorm stage; coef = [cA|cB|cC])
+// gy = g' = gz * act'(y)                                     (scale == nullptr: activation only)
+// The grid-stride (a multiple of 256 items) is a multiple of C/8, so a lane keeps its channel octet
+// for the whole loop and the per-channel vectors are loaded once.
 __global__ void __launch_bounds__(256)
 bn_bwd_apply_kernel(const uint4 *__restrict__ gz, const uint4 *__restrict__ y, const float *__restrict__ scale,
-                    const float *__restrict__ shift, const float *__restrict__ mean, const float *__restrict__ invstd,
-                    const float *__restrict__ dgamma, const float *__restrict__ dbeta, uint4 *__restrict__ gy,
-                    long total8, int C8, float inv_n, int act, int dt) {
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total8; i += (long)gridDim.x * blockDim.x) {
-        const int c0 = (int)(i % C8) * 8;
+                    const float *__restrict__ shift, const float *__restrict__ coef, uint4 *__restrict__ gy,
+                    long total8, int C8, int act, int dt) {
+    const long i0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const int c0 = (int)(i0 % C8) * 8, C = C8 * 8;
+    float sc[8], sh[8], cA[8], cB[8], cC[8];
+    if (scale) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 a = *reinterpret_cast<const float4 *>(scale + c0 + 4 * h), b = *reinterpret_cast<const float4 *>(shift + c0 + 4 * h);
+            const float4 k0 = *reinterpret_cast<const float4 *>(coef + c0 + 4 * h), k1 = *reinterpret_cast<const float4 *>(coef + C + c0 + 4 * h),
+                         k2 = *reinterpret_cast<const float4 *>(coef + 2 * C + c0 + 4 * h);
+            sc[4 * h] = a.x; sc[4 * h + 1] = a.y; sc[4 * h + 2] = a.z; sc[4 * h + 3] = a.w;
+            sh[4 * h] = b.x; sh[4 * h + 1] = b.y; sh[4 * h + 2] = b.z; sh[4 * h + 3] = b.w;
+            cA[4 * h] = k0.x; cA[4 * h + 1] = k0.y; cA[4 * h + 2] = k0.z; cA[4 * h + 3] = k0.w;
+            cB[4 * h] = k1.x; cB[4 * h + 1] = k1.y; cB[4 * h + 2] = k1.z; cB[4 * h + 3] = k1.w;
+            cC[4 * h] = k2.x; cC[4 * h + 1] = k2.y; cC[4 * h + 2] = k2.z; cC[4 * h + 3] = k2.w;
+        }
+    }
+    for (long i = i0; i < total8; i += (long)gridDim.x * blockDim.x) {
         float g[8], v[8], o[8];
         unpack8(gz[i], g, dt);
         unpack8(y[i], v, dt);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int c = c0 + j;
-            if (scale) {
-                const float sc = scale[c];
-                float gp = act_grad(g[j], v[j] * sc + shift[c], act);
-                float yh = (v[j] - mean[c]) * invstd[c];
-                o[j] = sc * (gp - dbeta[c] * inv_n - yh * dgamma[c] * inv_n);
-            } else {
-                o[j] = act_grad(g[j], v[j], act);
-            }
+            if (scale) o[j] = cA[j] * act_grad(g[j], v[j] * sc[j] + sh[j], act) + cB[j] * v[j] + cC[j];
+            else o[j] = act_grad(g[j], v[j], act);
         }
         gy[i] = pack8(o, dt);
     }
@@ -201,10 +220,16 @@ xexpand_bwd_kernel(const uint16_t *__restrict__ dxe, float *__restrict__ din, in
     }
 }
 
+static long bn_bwd_pixels_per_block(long npix, int C) {
+    const long rows = 256 / (C / 8);                 // pixel rows one block covers per loop iteration
+    long per = (npix + 1023) / 1024;                 // aim for ~1024 blocks
+    per = ((per + rows - 1) / rows) * rows;
+    return per < rows ? rows : per;
+}
+
 extern "C" int ir2rgb_bn_bwd_blocks(long npix, int C) {
     if (npix < 1 || C < 64 || (C & (C - 1)) || C > 2048) return IR2RGB_EINVAL;
-    long per = 256;  // pixels per block, grown until <= 1024 blocks
-    while ((npix + per - 1) / per > 1024) per *= 2;
+    const long per = bn_bwd_pixels_per_block(npix, C);
     return (int)((npix + per - 1) / per);
 }
 
@@ -215,18 +240,17 @@ extern "C" int ir2rgb_bn_bwd(const void *gz, const void *y, const float *scale, 
     if (nblk < 0) return nblk;
     if (dtype != IR2RGB_BF16 && dtype != IR2RGB_F16) return IR2RGB_ENOSUP;
     if (!gz || !y || !gy || !dgamma || !dbeta || !partial || act < 0 || act > 2) return IR2RGB_EINVAL;
-    long per = (npix + nblk - 1) / nblk;
-    // per must match the partition used to size `partial`: recompute exactly as ir2rgb_bn_bwd_blocks did
-    per = 256;
-    while ((npix + per - 1) / per > 1024) per *= 2;
+    const long per = bn_bwd_pixels_per_block(npix, C);
     hipStream_t s = as_stream(stream);
+    // partial holds nblk*2*C floats followed by 3*C coefficient floats (see ir2rgb_hip.h)
+    float *coef = partial + (long)nblk * 2 * C;
     bn_bwd_reduce_kernel<<<nblk, 256, 0, s>>>((const uint4 *)gz, (const uint4 *)y, scale, shift, mean, invstd, partial,
                                               npix, C, act, dtype, per);
-    bn_bwd_finalize_kernel<<<cdiv(C, 32), 1024, 0, s>>>(partial, nblk, C, dgamma, dbeta);
+    bn_bwd_finalize_kernel<<<cdiv(C, 32), 1024, 0, s>>>(partial, nblk, C, scale, mean, invstd, 1.0f / (float)npix, dgamma,
+                                                        dbeta, coef);
     long total8 = npix * (C / 8);
-    bn_bwd_apply_kernel<<<stream_grid(total8, 256), 256, 0, s>>>((const uint4 *)gz, (const uint4 *)y, scale, shift, mean,
-                                                                 invstd, dgamma, dbeta, (uint4 *)gy, total8, C / 8,
-                                                                 1.0f / (float)npix, act, dtype);
+    bn_bwd_apply_kernel<<<stream_grid(total8, 256), 256, 0, s>>>((const uint4 *)gz, (const uint4 *)y, scale, shift, coef,
+                                                                 (uint4 *)gy, total8, C / 8, act, dtype);
     return ir2rgb_launch_status();
 }
 

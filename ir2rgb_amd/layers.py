@@ -72,8 +72,19 @@ def bn_finalize(stats, count, bn, training=True):
                                            _p(scale), _p(shift), _p(mean), _p(invstd), _lib.current_stream(stats))
     _lib.check(rc, "bn_finalize")
     if track and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+        _PENDING_COUNTERS.append(bn.num_batches_tracked)
     return scale, shift, mean, invstd
+
+
+_PENDING_COUNTERS = []
+
+
+def flush_bn_counters():
+    """num_batches_tracked += 1 for every BatchNorm touched since the last flush -- one fused launch
+    (called at the end of each generator / discriminator forward)."""
+    if _PENDING_COUNTERS:
+        torch._foreach_add_(_PENDING_COUNTERS, 1)
+        _PENDING_COUNTERS.clear()
 
 
 def bn_apply(x, scale, shift, act=ACT_NONE, res1=None, res2=None, out=None):

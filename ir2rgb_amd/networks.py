@@ -222,6 +222,7 @@ class CompositeGeneratorModule(_CompositeBase):
         if not self.no_flow:
             flow_feat = _run_sequence(self.model_up_flow, _run_sequence(self.model_res_flow, downsample, dt, tr), dt, tr)
         img_final, flow, weight, img_raw = self._heads_and_blend(img_feat, flow_feat, img_prev, use_raw_only, 20.0)
+        L.flush_bn_counters()
         return img_final, flow, weight, img_raw, img_feat, flow_feat, None
 
 
@@ -271,6 +272,7 @@ class CompositeLocalGeneratorModule(_CompositeBase):
             flow_feat = _run_sequence(self.model_up_flow, flow_in, dt, tr)
         img_final, flow, weight, img_raw = self._heads_and_blend(img_feat, flow_feat, img_prev, use_raw_only,
                                                                  20.0 * (2 ** self.scale))
+        L.flush_bn_counters()
         return img_final, flow, weight, img_raw, img_feat, flow_feat, None
 
 
@@ -357,6 +359,7 @@ class MultiScaleDiscriminator(nn.Module):
             result.append(outs if self.getIntermFeat else [outs[-1]])
             if i != self.num_D - 1:
                 x = self.downsample(x)
+        L.flush_bn_counters()
         return result
 
 
