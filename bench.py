@@ -125,7 +125,7 @@ def main():
     avg = tot / n_launch
     achieved = rec["flops"] / avg / 1e12
     roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": None,  # PMC passes cover the 64x128 hot shape only: profiles/r01_conv_hot_pmc_summary.txt
                 "kernel": "conv_igemm_kernel (MFMA implicit GEMM)",
                 "shape": dict(zip(("Cin", "Hin", "Win", "Cout", "kh", "kw", "stride", "reflect", "transposed"), key)),
                 "launches": n_launch, "avg_us": round(avg * 1e6, 1), "flops_per_launch": rec["flops"]}

@@ -43,10 +43,22 @@ def avg_pool_pyramid(t, n_scales):
     return out
 
 
+_GRID_CACHE = {}
+
+
+def _grid(b, h, w, device, dtype):
+    """get_grid once per shape: the lattice is built on the host, so re-creating it costs a synchronous
+    host-to-device copy per call (the reference caches it on the module too, base_model.py:131-132)."""
+    key = (b, h, w, str(device), dtype)
+    if key not in _GRID_CACHE:
+        _GRID_CACHE[key] = networks.get_grid(b, h, w, device=device, dtype=dtype)
+    return _GRID_CACHE[key]
+
+
 def resample(image, flow):
     """Model.resample (base_model.py:129-136): same align_corners mismatch as the generator's warp."""
     b, c, h, w = image.shape
-    grid = networks.get_grid(b, h, w, device=flow.device, dtype=flow.dtype)
+    grid = _grid(b, h, w, flow.device, flow.dtype)
     fl = torch.cat([flow[:, 0:1] / ((w - 1.0) / 2.0), flow[:, 1:2] / ((h - 1.0) / 2.0)], 1)
     return F.grid_sample(image, (grid + fl).permute(0, 2, 3, 1), mode="bilinear", padding_mode="border", align_corners=False)
 
