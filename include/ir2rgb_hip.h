@@ -117,8 +117,12 @@ typedef struct ir2rgb_conv_desc {
     int pad_mode;           /* 0: zero padding, 1: reflection padding (nn.ReflectionPad2d) */
     int transposed;         /* 0: Conv2d, 1: ConvTranspose2d (stride 1 or 2 per axis; Hout/Wout carry output_padding) */
     int dtype;              /* IR2RGB_BF16 or IR2RGB_F16: activations and packed weights */
-    int act;                /* fused after bias: 0 none, 1 LeakyReLU(0.2) */
+    int act;                /* fused after bias: 0 none, 1 LeakyReLU(0.2), 2 LeakyReLU(0.1) */
     int out_f32;            /* 0: y is half NHWC, 1: y is fp32 NHWC (head convolutions) */
+    /* channel-slice views (0 = dense): x holds ldx channels per pixel of which [ci_off, ci_off+Cin) are
+     * read; y holds ldy channels per pixel of which [co_off, co_off+Cout) are written.  Lets producers
+     * write straight into the concatenation buffers of the FlowNet2 decoders (torch.cat, FlowNetS.py etc.) */
+    int ldx, ci_off, ldy, co_off;
 } ir2rgb_conv_desc;
 
 /* Number of half elements of the packed weight buffer for this convolution (< 0: error). */
@@ -167,6 +171,14 @@ int ir2rgb_nhwc_half_to_nchw_f32(const void *in, float *out, int N, int C, int H
  * :253-255; Conv4x4 s2 p2 on 6/13 channels, :680) into KH x 1 convolutions for the MFMA kernel. */
 int ir2rgb_xexpand(const float *in, void *out, int N, int Cin, int H, int W, int Wout, int KW, int stride_w,
                    int pad_w, int pad_mode, int dtype, void *stream);
+/* Same with Cx = 64 or 128 output channels (Cin*KW <= Cx): the 12-channel 7x7 first layer of FlowNetS. */
+int ir2rgb_xexpand_cx(const float *in, void *out, int N, int Cin, int H, int W, int Wout, int KW, int stride_w,
+                      int pad_w, int pad_mode, int Cx, int dtype, void *stream);
+
+/* NCHW fp32 [N,C,H,W] -> channels [c_off, c_off+C) of an NHWC half buffer with ld channels per pixel,
+ * with an optional fused activation (0 none, 2 LeakyReLU(0.1): corr_activation, FlowNetC.py:32). */
+int ir2rgb_nchw_f32_to_nhwc_half_slice(const float *in, void *out, int N, int C, int H, int W, int ld, int c_off,
+                                       int act, int dtype, void *stream);
 
 /* Finish of a separable head: T [N,H,W,CT] fp32 holds, in channel co*KH+ky, the horizontal
  * part of a KHxKW convolution; out[n][co][y][x] = f(sum_ky T[n][refl(y+ky-pad)][x][co*KH+ky] + bias[co]).

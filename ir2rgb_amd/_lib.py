@@ -18,7 +18,8 @@ P = c_void_p  # device pointer
 class ConvDesc(ctypes.Structure):
     """ir2rgb_conv_desc of include/ir2rgb_hip.h."""
     _fields_ = [(n, c_int) for n in ("N", "Hin", "Win", "Cin", "Hout", "Wout", "Cout", "kh", "kw", "stride_h", "stride_w",
-                                     "pad_h", "pad_w", "pad_mode", "transposed", "dtype", "act", "out_f32")]
+                                     "pad_h", "pad_w", "pad_mode", "transposed", "dtype", "act", "out_f32",
+                                     "ldx", "ci_off", "ldy", "co_off")]
 
 
 _pdesc = ctypes.POINTER(ConvDesc)
@@ -44,6 +45,8 @@ PROTOTYPES = {
     "ir2rgb_nchw_f32_to_nhwc_half": (c_int, [P, P] + [c_int] * 5 + [P]),
     "ir2rgb_nhwc_half_to_nchw_f32": (c_int, [P, P] + [c_int] * 5 + [P]),
     "ir2rgb_xexpand": (c_int, [P, P] + [c_int] * 10 + [P]),
+    "ir2rgb_xexpand_cx": (c_int, [P, P] + [c_int] * 11 + [P]),
+    "ir2rgb_nchw_f32_to_nhwc_half_slice": (c_int, [P, P] + [c_int] * 8 + [P]),
     "ir2rgb_head_finish": (c_int, [P, P, P] + [c_int] * 7 + [ctypes.c_uint, c_float, P]),
     "ir2rgb_warp_blend_fwd": (c_int, [P] * 6 + [c_int] * 4 + [P]),
     "ir2rgb_bn_bwd_blocks": (c_int, [c_long, c_int]),

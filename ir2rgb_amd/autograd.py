@@ -124,7 +124,7 @@ def conv_dgrad(gy, conv, spec, x_shape, weight_fn=None, tag="dgrad"):
         raise NotImplementedError("data gradient of a strided reflect-padded convolution")
     hfull, wfull = (gy.shape[2] - 1) * sh - 2 * ph + kh, (gy.shape[3] - 1) * sw - 2 * pw + kw
     desc = C.ConvDesc(n, gy.shape[2], gy.shape[3], gy.shape[1], hin, win, cin, kh, kw, sh, sw, ph, pw, C.PAD_ZERO, 1,
-                      _DT[dt], 0, 0)
+                      _DT[dt], 0, 0, 0, 0, 0, 0)
     assert 0 <= hin - hfull < sh and 0 <= win - wfull < sw, "adjoint geometry mismatch"
     wp = L.packed_weight(conv, desc, weight_fn, tag=tag)
     dx, _ = C.conv2d_fwd(desc, gy, wp)

@@ -32,14 +32,14 @@ def _pair(v):
 
 
 def make_desc(x_shape, cout, k, stride, pad, pad_mode, dtype, transposed=False, output_padding=0, act=ACT_NONE,
-              out_f32=False):
+              out_f32=False, ldx=0, ci_off=0, ldy=0, co_off=0):
     """x_shape = (N, Cin, H, W) logical; k / stride / pad = int or (h, w) pair."""
     n, cin, h, w = x_shape
     (kh, kw), (sh, sw), (ph, pw) = _pair(k), _pair(stride), _pair(pad)
     ho = out_size(h, kh, sh, ph, transposed, output_padding)
     wo = out_size(w, kw, sw, pw, transposed, output_padding)
     return ConvDesc(n, h, w, cin, ho, wo, cout, kh, kw, sh, sw, ph, pw, pad_mode, int(transposed), _TORCH2DT[dtype],
-                    act, int(out_f32))
+                    act, int(out_f32), ldx, ci_off, ldy, co_off)
 
 
 def is_nhwc(t):
@@ -133,3 +133,22 @@ def conv2d_wgrad(desc, x, gy):
         rc = lib.ir2rgb_conv2d_wgrad(ctypes.byref(desc), _p(x), _p(gy), _p(dw), _p(ws), _lib.current_stream(x))
     _lib.check(rc, "conv2d_wgrad")
     return dw
+
+
+def conv2d_fwd_view(desc, xbuf, wpacked, bias, ybuf, stats=None):
+    """Raw launch on caller-owned buffers (channel-slice views: desc.ldx/ci_off/ldy/co_off).  No shape
+    checks beyond device / alignment: the caller (flownet2_hip) owns the buffer geometry."""
+    if not (xbuf.is_cuda and ybuf.is_cuda):
+        raise ValueError("conv2d_fwd_view: GPU tensors only (no CPU fallback)")
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    with torch.cuda.device_of(xbuf):
+        rc = _lib.lib().ir2rgb_conv2d_fwd(ctypes.byref(desc), _p(xbuf), _p(wpacked), _p(bias), _p(ybuf), _p(stats),
+                                          _lib.current_stream(xbuf))
+    _lib.check(rc, "conv2d_fwd")
+    if prof is not None:
+        e1.record()
+        key = (desc.Cin, desc.Hin, desc.Win, desc.Cout, desc.kh, desc.kw, desc.stride_h, desc.pad_mode, desc.transposed)
+        prof.setdefault(key, {"flops": _flops(desc), "events": []})["events"].append((e0, e1))

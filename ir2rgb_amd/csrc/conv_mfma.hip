@@ -48,7 +48,8 @@ struct ConvGeom {
     int s_out_y, s_out_x, off_y, off_x;  // output coordinate = sub * s_out + off
     int ntaps, pad_mode;      // pad_mode 0: zeros outside, 1: reflect (no edge repeat)
     int kchunks;              // Cin / 64
-    int act;                  // 0: none, 1: LeakyReLU(0.2) after bias
+    int act;                  // 0: none, 1: LeakyReLU(0.2), 2: LeakyReLU(0.1) after bias
+    int ldx, ci_off, ldy, co_off;  // channel-slice views: pixel stride (elements) and first channel of X / Y
     int stats_row0;           // first row of stats_partial written by this launch
     int out_f32;              // 1: Y is fp32 NHWC (head convolutions), 0: half
     unsigned x_bytes, w_bytes; // extents of X and of this class's packed weights (buffer resources, < 2^31)
@@ -177,7 +178,7 @@ conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W
         const bool inb = ((unsigned)iy < (unsigned)g.Hin) & ((unsigned)ix < (unsigned)g.Win);
         iy = g.pad_mode ? reflect(iy, g.Hin) : iy;
         ix = g.pad_mode ? reflect(ix, g.Win) : ix;
-        const unsigned off = ((pbase[i] + (unsigned)(iy * g.Win + ix)) * (unsigned)g.Cin + chunk * 8) * 2u;
+        const unsigned off = ((pbase[i] + (unsigned)(iy * g.Win + ix)) * (unsigned)g.ldx + g.ci_off + chunk * 8) * 2u;
         return (g.pad_mode || inb) ? off : IR2RGB_OOB;
     };
 
@@ -322,11 +323,11 @@ conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 v[r] = acc[mi][ni][r] + bv[r];
-                if (g.act == 1) v[r] = v[r] > 0.f ? v[r] : 0.2f * v[r];
+                if (g.act) v[r] = v[r] > 0.f ? v[r] : (g.act == 1 ? 0.2f : 0.1f) * v[r];
                 if (oval[ni]) { s1[r] += v[r]; s2[r] += v[r] * v[r]; }
             }
             if (oval[ni] && g.out_f32) {
-                float *dst = reinterpret_cast<float *>(Y) + opix[ni] * g.Cout + co;
+                float *dst = reinterpret_cast<float *>(Y) + opix[ni] * g.ldy + g.co_off + co;
                 if (co + 3 < g.Cout && (g.Cout & 3) == 0) {
                     *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
@@ -335,7 +336,7 @@ conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W
                         if (co + r < g.Cout) dst[r] = v[r];
                 }
             } else if (oval[ni]) {
-                uint16_t *dst = Y + opix[ni] * g.Cout + co;
+                uint16_t *dst = Y + opix[ni] * g.ldy + g.co_off + co;
                 if (co + 3 < g.Cout && (g.Cout & 3) == 0) {
                     uint2 pk;
                     pk.x = (uint32_t)H::cvt(v[0]) | ((uint32_t)H::cvt(v[1]) << 16);
@@ -508,12 +509,18 @@ static int make_plan(const ir2rgb_conv_desc *d, ClassPlan plans[4]) {
             }
     }
     if ((long)d->N * d->Hin * d->Win >= (1L << 31) || (long)d->N * d->Hout * d->Wout >= (1L << 31) ||
-        (long)d->N * d->Hin * d->Win * (d->Cin / 8) >= 0xFFFFFFFFL)
+        (long)d->N * d->Hin * d->Win * ((d->ldx > 0 ? d->ldx : d->Cin) / 8) >= 0xFFFFFFFFL)
         return IR2RGB_EINVAL;
     for (int i = 0; i < ncls; ++i) {
         ConvGeom &g = plans[i].geom;
         g.variant = conv_variant();
-        const long xb = (long)g.N * g.Hin * g.Win * g.Cin * 2, wb = (long)g.Cout * g.Cin * g.ntaps * 2;
+        g.ldx = d->ldx > 0 ? d->ldx : d->Cin; g.ci_off = d->ci_off;
+        g.ldy = d->ldy > 0 ? d->ldy : d->Cout; g.co_off = d->co_off;
+        if (g.ci_off < 0 || g.co_off < 0 || g.ci_off + d->Cin > g.ldx || g.co_off + d->Cout > g.ldy || (g.ldx & 7) || (g.ci_off & 7))
+            return IR2RGB_EINVAL;
+        // the epilogue's 4-channel vector stores (taken when Cout % 4 == 0) need 4-channel aligned rows
+        if ((d->Cout & 3) == 0 && ((g.ldy & 3) || (g.co_off & 3))) return IR2RGB_EINVAL;
+        const long xb = (long)g.N * g.Hin * g.Win * g.ldx * 2, wb = (long)g.Cout * g.Cin * g.ntaps * 2;
         if (xb >= (1L << 31) || wb >= (1L << 31)) return IR2RGB_EINVAL;  // 32-bit buffer offsets
         g.x_bytes = (unsigned)xb; g.w_bytes = (unsigned)wb;
         long P = (long)g.N * g.Hsub * g.Wsub;

@@ -105,6 +105,27 @@ bn_apply_kernel(const uint4 *__restrict__ x, const float *__restrict__ scale, co
 // ----------------------------------------------------------------------------------------
 template <int DT>
 __global__ void __launch_bounds__(256)
+nchw_to_nhwc_slice_kernel(const float *__restrict__ in, uint16_t *__restrict__ out, int C, long HW, int ld, int c_off,
+                          int act) {
+    __shared__ float tile[64][65];
+    const long p0 = (long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64, n = blockIdx.z;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int j = ty; j < 64; j += 4) {
+        int c = c0 + j; long p = p0 + tx;
+        float v = (c < C && p < HW) ? in[((long)n * C + c) * HW + p] : 0.f;
+        if (act == 2) v = v > 0.f ? v : 0.1f * v;
+        tile[j][tx] = v;
+    }
+    __syncthreads();
+    for (int j = ty; j < 64; j += 4) {
+        long p = p0 + j; int c = c0 + tx;
+        if (p < HW && c < C) out[((long)n * HW + p) * ld + c_off + c] = f2h(tile[tx][j], DT);
+    }
+}
+
+template <int DT>
+__global__ void __launch_bounds__(256)
 nchw_to_nhwc_kernel(const float *__restrict__ in, uint16_t *__restrict__ out, int C, long HW) {
     __shared__ float tile[64][65];
     const long p0 = (long)blockIdx.x * 64;
@@ -147,11 +168,11 @@ nhwc_to_nchw_kernel(const uint16_t *__restrict__ in, float *__restrict__ out, in
 template <int DT>
 __global__ void __launch_bounds__(256)
 xexpand_kernel(const float *__restrict__ in, uint4 *__restrict__ out, int Cin, int H, int W, int Wout, int KW,
-               int sx, int px, int pad_mode, long total) {
-    // total = N*H*Wout*8 (8 lanes per output pixel)
+               int sx, int px, int pad_mode, int lanes, long total) {
+    // total = N*H*Wout*lanes (lanes = Cx/8 lanes per output pixel)
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int j0 = (int)(i & 7) * 8;
-        long pix = i >> 3;
+        const int j0 = (int)(i % lanes) * 8;
+        long pix = i / lanes;
         const int ox = (int)(pix % Wout); pix /= Wout;
         const int y = (int)(pix % H);
         const int n = (int)(pix / H);
@@ -235,19 +256,39 @@ extern "C" int ir2rgb_nhwc_half_to_nchw_f32(const void *in, float *out, int N, i
     return ir2rgb_launch_status();
 }
 
-extern "C" int ir2rgb_xexpand(const float *in, void *out, int N, int Cin, int H, int W, int Wout, int KW, int stride_w,
-                              int pad_w, int pad_mode, int dtype, void *stream) {
-    if (N < 0 || Cin < 1 || H < 1 || W < 1 || Wout < 1 || KW < 1 || Cin * KW > 64 || stride_w < 1 || pad_w < 0)
+extern "C" int ir2rgb_xexpand_cx(const float *in, void *out, int N, int Cin, int H, int W, int Wout, int KW,
+                                 int stride_w, int pad_w, int pad_mode, int Cx, int dtype, void *stream) {
+    if (N < 0 || Cin < 1 || H < 1 || W < 1 || Wout < 1 || KW < 1 || (Cx != 64 && Cx != 128) || Cin * KW > Cx ||
+        stride_w < 1 || pad_w < 0)
         return IR2RGB_EINVAL;
     if (pad_mode == 1 && pad_w >= W) return IR2RGB_EINVAL;
     if ((Wout - 1) * stride_w + KW - pad_w > W + pad_w) return IR2RGB_EINVAL;  // would read past the padded row
     if (dtype != IR2RGB_BF16 && dtype != IR2RGB_F16) return IR2RGB_ENOSUP;
-    long total = (long)N * H * Wout * 8;
+    const int lanes = Cx / 8;
+    long total = (long)N * H * Wout * lanes;
     if (total == 0) return IR2RGB_OK;
     int grid = stream_grid(total, 256);
     if (dtype == IR2RGB_BF16)
-        xexpand_kernel<IR2RGB_BF16><<<grid, 256, 0, as_stream(stream)>>>(in, (uint4 *)out, Cin, H, W, Wout, KW, stride_w, pad_w, pad_mode, total);
+        xexpand_kernel<IR2RGB_BF16><<<grid, 256, 0, as_stream(stream)>>>(in, (uint4 *)out, Cin, H, W, Wout, KW, stride_w, pad_w, pad_mode, lanes, total);
     else
-        xexpand_kernel<IR2RGB_F16><<<grid, 256, 0, as_stream(stream)>>>(in, (uint4 *)out, Cin, H, W, Wout, KW, stride_w, pad_w, pad_mode, total);
+        xexpand_kernel<IR2RGB_F16><<<grid, 256, 0, as_stream(stream)>>>(in, (uint4 *)out, Cin, H, W, Wout, KW, stride_w, pad_w, pad_mode, lanes, total);
     return ir2rgb_launch_status();
 }
+
+extern "C" int ir2rgb_xexpand(const float *in, void *out, int N, int Cin, int H, int W, int Wout, int KW, int stride_w,
+                              int pad_w, int pad_mode, int dtype, void *stream) {
+    return ir2rgb_xexpand_cx(in, out, N, Cin, H, W, Wout, KW, stride_w, pad_w, pad_mode, 64, dtype, stream);
+}
+
+extern "C" int ir2rgb_nchw_f32_to_nhwc_half_slice(const float *in, void *out, int N, int C, int H, int W, int ld,
+                                                  int c_off, int act, int dtype, void *stream) {
+    if (N < 0 || C < 1 || H < 1 || W < 1 || ld < C || c_off < 0 || c_off + C > ld || (act != 0 && act != 2)) return IR2RGB_EINVAL;
+    if (dtype != IR2RGB_BF16 && dtype != IR2RGB_F16) return IR2RGB_ENOSUP;
+    if (N == 0) return IR2RGB_OK;
+    long HW = (long)H * W;
+    dim3 grid((unsigned)cdiv(HW, 64), (unsigned)cdiv(C, 64), (unsigned)N);
+    if (dtype == IR2RGB_BF16) nchw_to_nhwc_slice_kernel<IR2RGB_BF16><<<grid, 256, 0, as_stream(stream)>>>(in, (uint16_t *)out, C, HW, ld, c_off, act);
+    else nchw_to_nhwc_slice_kernel<IR2RGB_F16><<<grid, 256, 0, as_stream(stream)>>>(in, (uint16_t *)out, C, HW, ld, c_off, act);
+    return ir2rgb_launch_status();
+}
+

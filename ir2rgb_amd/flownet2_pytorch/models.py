@@ -193,8 +193,16 @@ class FlowNet2(nn.Module):
         self.flownetfusion = FlowNetFusion()
         _flownet_init(self)
 
+    use_hip_convs = True  # False: torch convolutions (kept as the GPU reference for tests/test_flownet2_gpu.py)
+
     def _net(self, net, x):
-        """torch convolution stack in conv_dtype / channels_last; result back in fp32."""
+        """One sub-network.  Product path: the MFMA engine of ir2rgb_amd/flownet2_hip.py; test reference:
+        the torch convolution stack in conv_dtype / channels_last.  Result in fp32 either way."""
+        if self.use_hip_convs:
+            from .. import flownet2_hip as FH
+            run = {FlowNetC: FH.flownetc, FlowNetS: FH.flownets, FlowNetSD: FH.flownetsd, FlowNetFusion: FH.flownetfusion}
+            dt = torch.bfloat16 if self.conv_dtype == torch.float32 else self.conv_dtype
+            return run[type(net)](net, x.float().contiguous(), dt)
         if self.conv_dtype == torch.float32:
             return net(x)
         with torch.autocast("cuda", dtype=self.conv_dtype):

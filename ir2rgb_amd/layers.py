@@ -128,28 +128,28 @@ def to_nchw_f32(x):
     return y
 
 
-def xexpand(x, kw, stride_w, pad_w, pad_mode, dtype):
-    """NCHW fp32 [N,Cin,H,W] -> channels_last half [N,64,H,Wout] with channel ci*kw+kx = x[ci][.., ox*s+kx-p]."""
+def xexpand(x, kw, stride_w, pad_w, pad_mode, dtype, cx=64):
+    """NCHW fp32 [N,Cin,H,W] -> channels_last half [N,cx,H,Wout] with channel ci*kw+kx = x[ci][.., ox*s+kx-p]."""
     _require_gpu(x, "xexpand")
     x = x.float().contiguous()
     n, cin, h, w = x.shape
     wout = (w + 2 * pad_w - kw) // stride_w + 1
-    y = C.empty_nhwc(n, 64, h, wout, dtype, x.device)
+    y = C.empty_nhwc(n, cx, h, wout, dtype, x.device)
     with torch.cuda.device_of(x):
-        rc = _lib.lib().ir2rgb_xexpand(_p(x), _p(y), n, cin, h, w, wout, kw, stride_w, pad_w, pad_mode, _DT[dtype],
-                                       _lib.current_stream(x))
+        rc = _lib.lib().ir2rgb_xexpand_cx(_p(x), _p(y), n, cin, h, w, wout, kw, stride_w, pad_w, pad_mode, cx, _DT[dtype],
+                                          _lib.current_stream(x))
     _lib.check(rc, "xexpand")
     return y
 
 
-def _xexpanded_weight(kw):
-    """[Cout,Cin,kh,kw] -> [Cout,64,kh,1] with input channel ci*kw+kx (zero padded to 64)."""
+def _xexpanded_weight(kw, cx=64):
+    """[Cout,Cin,kh,kw] -> [Cout,cx,kh,1] with input channel ci*kw+kx (zero padded to cx)."""
     def f(w):
         co, ci, kh, kw_ = w.shape
-        assert kw_ == kw and ci * kw <= 64
+        assert kw_ == kw and ci * kw <= cx
         v = w.permute(0, 2, 1, 3).reshape(co, kh, ci * kw)       # [co][ky][ci*kw+kx]
-        v = torch.nn.functional.pad(v, (0, 64 - ci * kw))        # [co][ky][64]
-        return v.permute(0, 2, 1).unsqueeze(-1)                  # [co][64][ky][1]
+        v = torch.nn.functional.pad(v, (0, cx - ci * kw))        # [co][ky][cx]
+        return v.permute(0, 2, 1).unsqueeze(-1)                  # [co][cx][ky][1]
     return f
 
 
