@@ -243,6 +243,12 @@ long ir2rgb_conv2d_wgrad_workspace_elems(const ir2rgb_conv_desc *d);
 int ir2rgb_conv2d_wgrad(const ir2rgb_conv_desc *d, const void *x, const void *gy, float *dw, float *workspace,
                         void *stream);
 
+/* FlowNet2 flow up-sampler ConvTranspose2d(2,2,4,2,1) (reference FlowNetC.py:47-50 etc.): in [N,2,h,w]
+ * fp32 NCHW, weight [2,2,4,4], bias [2] or NULL -> channels [c_off, c_off+2) of an NHWC half buffer
+ * [N,2h,2w,ld]. */
+int ir2rgb_flow_upsample_slice(const float *in, const float *weight, const float *bias, void *out, int N, int h,
+                               int w, int ld, int c_off, int dtype, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,7 @@ PROTOTYPES = {
     "ir2rgb_xexpand": (c_int, [P, P] + [c_int] * 10 + [P]),
     "ir2rgb_xexpand_cx": (c_int, [P, P] + [c_int] * 11 + [P]),
     "ir2rgb_nchw_f32_to_nhwc_half_slice": (c_int, [P, P] + [c_int] * 8 + [P]),
+    "ir2rgb_flow_upsample_slice": (c_int, [P, P, P, P] + [c_int] * 6 + [P]),
     "ir2rgb_head_finish": (c_int, [P, P, P] + [c_int] * 7 + [ctypes.c_uint, c_float, P]),
     "ir2rgb_warp_blend_fwd": (c_int, [P] * 6 + [c_int] * 4 + [P]),
     "ir2rgb_bn_bwd_blocks": (c_int, [c_long, c_int]),

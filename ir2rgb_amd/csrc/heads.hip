@@ -219,3 +219,51 @@ extern "C" int ir2rgb_warp_blend_bwd(const float *gout, const float *raw, const 
                                                                                   Cp, H, W, total);
     return ir2rgb_launch_status();
 }
+
+// ----------------------------------------------------------------------------------------
+// FlowNet2 flow up-sampler: ConvTranspose2d(2, 2, kernel 4, stride 2, padding 1) on a 2-channel fp32
+// flow (reference FlowNetC.py:47-50, FlowNetS.py:42-45 ...), written as NHWC half into channels
+// [c_off, c_off+2) of a concatenation buffer.  8 MACs per output: one lane per output pixel.
+// ----------------------------------------------------------------------------------------
+template <int DT>
+__global__ void __launch_bounds__(256)
+flow_up_kernel(const float *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
+               uint16_t *__restrict__ out, int h, int w, int ld, int c_off, long total) {
+    const int H = 2 * h, W = 2 * w;
+    const long hw = (long)h * w, HW = (long)H * W;
+    for (long g = blockIdx.x * (long)blockDim.x + threadIdx.x; g < total; g += (long)gridDim.x * blockDim.x) {
+        long n = g / HW, p = g - n * HW;
+        int oy = (int)(p / W), ox = (int)(p - (long)oy * W);
+        float acc[2] = {bias ? bias[0] : 0.f, bias ? bias[1] : 0.f};
+        for (int ky = (oy + 1) & 1; ky < 4; ky += 2) {
+            int iy = (oy + 1 - ky) / 2;  // oy = 2*iy - 1 + ky
+            if (oy + 1 - ky < 0 || iy >= h) continue;
+            for (int kx = (ox + 1) & 1; kx < 4; kx += 2) {
+                int ix = (ox + 1 - kx) / 2;
+                if (ox + 1 - kx < 0 || ix >= w) continue;
+                for (int ci = 0; ci < 2; ++ci) {
+                    float v = in[(n * 2 + ci) * hw + (long)iy * w + ix];
+                    acc[0] += v * wgt[((ci * 2 + 0) * 4 + ky) * 4 + kx];
+                    acc[1] += v * wgt[((ci * 2 + 1) * 4 + ky) * 4 + kx];
+                }
+            }
+        }
+        uint16_t h0, h1;
+        if (DT == IR2RGB_BF16) { __bf16 a = (__bf16)acc[0], b = (__bf16)acc[1]; h0 = __builtin_bit_cast(uint16_t, a); h1 = __builtin_bit_cast(uint16_t, b); }
+        else { _Float16 a = (_Float16)acc[0], b = (_Float16)acc[1]; h0 = __builtin_bit_cast(uint16_t, a); h1 = __builtin_bit_cast(uint16_t, b); }
+        uint16_t *dst = out + g * ld + c_off;
+        dst[0] = h0; dst[1] = h1;
+    }
+}
+
+extern "C" int ir2rgb_flow_upsample_slice(const float *in, const float *weight, const float *bias, void *out, int N,
+                                          int h, int w, int ld, int c_off, int dtype, void *stream) {
+    if (N < 0 || h < 1 || w < 1 || ld < 2 || c_off < 0 || c_off + 2 > ld) return IR2RGB_EINVAL;
+    if (dtype != IR2RGB_BF16 && dtype != IR2RGB_F16) return IR2RGB_ENOSUP;
+    long total = (long)N * 4 * h * w;
+    if (total == 0) return IR2RGB_OK;
+    int grid = stream_grid(total, 256);
+    if (dtype == IR2RGB_BF16) flow_up_kernel<IR2RGB_BF16><<<grid, 256, 0, as_stream(stream)>>>(in, weight, bias, (uint16_t *)out, h, w, ld, c_off, total);
+    else flow_up_kernel<IR2RGB_F16><<<grid, 256, 0, as_stream(stream)>>>(in, weight, bias, (uint16_t *)out, h, w, ld, c_off, total);
+    return ir2rgb_launch_status();
+}

@@ -9,8 +9,9 @@ concatenation buffers (ir2rgb_conv_desc.ldy / co_off) and consumers read slices 
 Concatenation widths that are not multiples of 64 (473, 1026, 770, 386, 194, 162, 82) are padded with
 zero channels in the buffer and zero columns in the packed weights.
 
-Left on torch (tiny 2-channel tensors): the ConvTranspose2d(2,2,4,2,1) flow up-samplers, the x4
-interpolations and the normalisation glue of FlowNet2.forward.
+The 2-channel ConvTranspose2d(2,2,4,2,1) flow up-samplers are a small direct kernel writing into the
+same buffers.  Left on torch (tiny 2..12-channel fp32 tensors): the x4 interpolations and the
+normalisation / concatenation glue of FlowNet2.forward.
 """
 import ctypes
 
@@ -109,6 +110,15 @@ def put_nchw(x_nchw, yv, act=0):
     _lib.check(rc, "nchw_f32_to_nhwc_half_slice")
 
 
+def flow_up(flow, mod, yv):
+    """ConvTranspose2d(2,2,4,2,1) of a 2-channel fp32 flow, written into a 2-channel slice of ``yv.buf``."""
+    n, _, h, w = flow.shape
+    with torch.cuda.device_of(flow):
+        rc = _lib.lib().ir2rgb_flow_upsample_slice(_p(flow), _p(mod.weight), _p(mod.bias), _p(yv.buf), n, h, w, yv.ld, yv.off,
+                                                   _DT[yv.buf.dtype], _lib.current_stream(flow))
+    _lib.check(rc, "flow_upsample_slice")
+
+
 def predict(xv, mod, n, h, w):
     """predict_flow (3x3, 2 channels): fp32 NCHW [N,2,h,w]."""
     out = torch.empty((n, 2, h, w), dtype=torch.float32, device=xv.buf.device).contiguous(memory_format=torch.channels_last)
@@ -140,11 +150,10 @@ class _Decoder:
         for lvl in (6, 5, 4, 3):
             h, w = feat.hw
             flow = predict(flow_in, getattr(net, f"predict_flow{lvl}"), n, h, w)
-            up = getattr(net, f"upsampled_flow{lvl}_to_{lvl - 1}")(flow)          # tiny 2-channel ConvTranspose2d (torch)
             nxt = self.cat[lvl - 1]
             so, do = self.SKIP[lvl - 1], self.DEC[lvl - 1]
             conv(feat, getattr(net, f"deconv{lvl - 1}")[0], View(nxt, so, do), LEAKY01, transposed=True)
-            put_nchw(up, View(nxt, so + do, 2))
+            flow_up(flow, getattr(net, f"upsampled_flow{lvl}_to_{lvl - 1}"), View(nxt, so + do, 2))
             feat = self.full_view(lvl - 1)
             if inter:
                 ic = getattr(net, f"inter_conv{lvl - 1}")[0]
@@ -226,11 +235,11 @@ def flownetfusion(net, x, dtype):
     c2 = conv(conv(c1, net.conv2[0], _dense(n, 128, H // 4, W // 4, dtype, dev), LEAKY01), net.conv2_1[0],
               _dense(n, 128, H // 4, W // 4, dtype, dev), LEAKY01)
     flow2 = predict(c2, net.predict_flow2, n, H // 4, W // 4)
-    put_nchw(net.upsampled_flow2_to_1(flow2), View(cat1, 160, 2))
+    flow_up(flow2, net.upsampled_flow2_to_1, View(cat1, 160, 2))
     conv(c2, net.deconv1[0], View(cat1, 128, 32), LEAKY01, transposed=True)
     i1 = conv(View(cat1, 0, 162), net.inter_conv1[0], _dense(n, 32, H // 2, W // 2, dtype, dev), 0)
     flow1 = predict(i1, net.predict_flow1, n, H // 2, W // 2)
-    put_nchw(net.upsampled_flow1_to_0(flow1), View(cat0, 80, 2))
+    flow_up(flow1, net.upsampled_flow1_to_0, View(cat0, 80, 2))
     conv(View(cat1, 0, 162), net.deconv0[0], View(cat0, 64, 16), LEAKY01, transposed=True)
     i0 = conv(View(cat0, 0, 82), net.inter_conv0[0], _dense(n, 16, H, W, dtype, dev), 0)
     return predict(i0, net.predict_flow0, n, H, W)
