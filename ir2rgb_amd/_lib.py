@@ -98,9 +98,37 @@ def check(rc, what):
         raise Ir2rgbError(f"{what}: HIP call failed (hipError_t {rc})")
 
 
+_RAW_STREAM = None
+
+
 def current_stream(tensor):
+    """hipStream_t of torch's current stream on the tensor's device (fast path: one C call)."""
+    global _RAW_STREAM
+    if _RAW_STREAM is None:
+        import torch
+        _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (
+            lambda idx: torch.cuda.current_stream(idx).cuda_stream)
+    return c_void_p(_RAW_STREAM(tensor.device.index))
+
+
+class _NullCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NULL = _NullCtx()
+
+
+def on_device(tensor):
+    """Context that makes the tensor's device current -- a no-op (no Python-level device switch) in the
+    one-process-per-GPU deployment where it already is."""
     import torch
-    return c_void_p(torch.cuda.current_stream(tensor.device).cuda_stream)
+    if tensor.device.index == torch.cuda.current_device():
+        return _NULL
+    return torch.cuda.device_of(tensor)
 
 
 def require_device(*tensors, dtype=None):

@@ -50,7 +50,7 @@ def bn_bwd(gz, y, scale, shift, mean, invstd, act):
     dgamma = torch.empty(ch, dtype=torch.float32, device=dev)
     dbeta = torch.empty(ch, dtype=torch.float32, device=dev)
     gy = torch.empty_like(y, memory_format=torch.channels_last)
-    with torch.cuda.device_of(y):
+    with _lib.on_device(y):
         rc = lib.ir2rgb_bn_bwd(_p(gz), _p(y), _p(scale), _p(shift), _p(mean), _p(invstd), _p(gy), _p(dgamma), _p(dbeta),
                                _p(partial), npix, ch, act, _DT[y.dtype], _lib.current_stream(y))
     _lib.check(rc, "bn_bwd")
@@ -62,7 +62,7 @@ def fold_reflect(dxpad, pad_h, pad_w=None):
     n, ch, hp, wp = dxpad.shape
     h, w = hp - 2 * pad_h, wp - 2 * pad_w
     dx = C.empty_nhwc(n, ch, h, w, dxpad.dtype, dxpad.device)
-    with torch.cuda.device_of(dxpad):
+    with _lib.on_device(dxpad):
         rc = _lib.lib().ir2rgb_fold_reflect(_p(dxpad), _p(dx), n, h, w, ch, pad_h, pad_w, _DT[dxpad.dtype],
                                             _lib.current_stream(dxpad))
     _lib.check(rc, "fold_reflect")
@@ -72,7 +72,7 @@ def fold_reflect(dxpad, pad_h, pad_w=None):
 def xexpand_bwd(dxe, cin, w, kw, stride_w, pad_w, pad_mode):
     n, _, h, wout = dxe.shape
     din = torch.empty((n, cin, h, w), dtype=torch.float32, device=dxe.device)
-    with torch.cuda.device_of(dxe):
+    with _lib.on_device(dxe):
         rc = _lib.lib().ir2rgb_xexpand_bwd(_p(dxe), _p(din), n, cin, h, w, wout, kw, stride_w, pad_w, pad_mode,
                                            _DT[dxe.dtype], _lib.current_stream(dxe))
     _lib.check(rc, "xexpand_bwd")
@@ -296,7 +296,7 @@ class HeadFn(Function):
         packed_acts = 0
         for i, a in enumerate(acts):
             packed_acts |= (a & 15) << (4 * i)
-        with torch.cuda.device_of(feat):
+        with _lib.on_device(feat):
             rc = _lib.lib().ir2rgb_head_finish_bwd(_p(gout), _p(out), _p(dT), _p(dbias), n, h, w, cout, kh, CT, kh // 2,
                                                    packed_acts, float(mul), _DT[feat.dtype], _lib.current_stream(feat))
         _lib.check(rc, "head_finish_bwd")
@@ -348,7 +348,7 @@ class WarpBlendFn(Function):
         gout = gout.float().contiguous()
         graw, gflow, gw = torch.empty_like(raw), torch.empty_like(flow), torch.empty_like(weight)
         n, _, h, w = raw.shape
-        with torch.cuda.device_of(raw):
+        with _lib.on_device(raw):
             rc = _lib.lib().ir2rgb_warp_blend_bwd(_p(gout), _p(raw), _p(prev), _p(flow), _p(weight), _p(graw), _p(gflow),
                                                   _p(gw), n, prev.shape[1], h, w, _lib.current_stream(raw))
         _lib.check(rc, "warp_blend_bwd")

@@ -60,7 +60,7 @@ def pack_weight(desc, weight, adjoint=False):
         _lib.check(int(n), "conv2d_packed_weight_elems")
     dt = torch.bfloat16 if desc.dtype == BF16 else torch.float16
     packed = torch.empty(n, dtype=dt, device=weight.device)
-    with torch.cuda.device_of(weight):
+    with _lib.on_device(weight):
         fn = lib.ir2rgb_conv2d_pack_weight_adjoint if adjoint else lib.ir2rgb_conv2d_pack_weight
         rc = fn(ctypes.byref(desc), _p(weight), _p(packed), _lib.current_stream(weight))
     _lib.check(rc, "conv2d_pack_weight")
@@ -104,7 +104,7 @@ def conv2d_fwd(desc, x, wpacked, bias=None, want_stats=False, out=None):
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    with torch.cuda.device_of(x):
+    with _lib.on_device(x):
         rc = _lib.lib().ir2rgb_conv2d_fwd(ctypes.byref(desc), _p(x), _p(wpacked), _p(bias), _p(y), _p(stats),
                                           _lib.current_stream(x))
     _lib.check(rc, "conv2d_fwd")
@@ -129,7 +129,7 @@ def conv2d_wgrad(desc, x, gy):
     ws = torch.empty(n, dtype=torch.float32, device=x.device)
     shape = (desc.Cin, desc.Cout, desc.kh, desc.kw) if desc.transposed else (desc.Cout, desc.Cin, desc.kh, desc.kw)
     dw = torch.empty(shape, dtype=torch.float32, device=x.device)
-    with torch.cuda.device_of(x):
+    with _lib.on_device(x):
         rc = lib.ir2rgb_conv2d_wgrad(ctypes.byref(desc), _p(x), _p(gy), _p(dw), _p(ws), _lib.current_stream(x))
     _lib.check(rc, "conv2d_wgrad")
     return dw
@@ -144,7 +144,7 @@ def conv2d_fwd_view(desc, xbuf, wpacked, bias, ybuf, stats=None):
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    with torch.cuda.device_of(xbuf):
+    with _lib.on_device(xbuf):
         rc = _lib.lib().ir2rgb_conv2d_fwd(ctypes.byref(desc), _p(xbuf), _p(wpacked), _p(bias), _p(ybuf), _p(stats),
                                           _lib.current_stream(xbuf))
     _lib.check(rc, "conv2d_fwd")

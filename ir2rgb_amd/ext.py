@@ -44,7 +44,7 @@ class correlation_cuda:
         if oh <= 0 or ow <= 0:
             raise ValueError("correlation: empty output for these parameters")
         output.resize_(N, oc, oh, ow)
-        with torch.cuda.device_of(input1):
+        with _lib.on_device(input1):
             rc = _lib.lib().ir2rgb_correlation_fwd(_p(input1), _p(input2), _p(output), N, C, H, W, pad_size,
                                                    kernel_size, max_displacement, stride1, stride2,
                                                    _lib.current_stream(input1))
@@ -63,7 +63,7 @@ class correlation_cuda:
             raise ValueError(f"correlation backward: gradOutput {tuple(gradOutput.shape)} != {(N, oc, oh, ow)}")
         gradInput1.resize_(N, C, H, W)
         gradInput2.resize_(N, C, H, W)
-        with torch.cuda.device_of(input1):
+        with _lib.on_device(input1):
             rc = _lib.lib().ir2rgb_correlation_bwd(_p(input1), _p(input2), _p(gradOutput), _p(gradInput1),
                                                    _p(gradInput2), N, C, H, W, pad_size, kernel_size,
                                                    max_displacement, stride1, stride2, _lib.current_stream(input1))
@@ -88,7 +88,7 @@ class resample2d_cuda:
         _lib.require_device(output, dtype=_f32)
         if tuple(output.shape) != (N, C, H, W):
             raise ValueError("resample2d: output has the wrong shape")
-        with torch.cuda.device_of(input1):
+        with _lib.on_device(input1):
             rc = _lib.lib().ir2rgb_resample2d_fwd(_p(input1), _p(input2), _p(output), N, C, H, W, kernel_size,
                                                   _lib.current_stream(input1))
         _lib.check(rc, "resample2d_cuda.forward")
@@ -98,7 +98,7 @@ class resample2d_cuda:
     def backward(input1, input2, gradOutput, gradInput1, gradInput2, kernel_size):
         N, C, H, W = resample2d_cuda._shapes(input1, input2)
         _lib.require_device(gradOutput, gradInput1, gradInput2, dtype=_f32)
-        with torch.cuda.device_of(input1):
+        with _lib.on_device(input1):
             rc = _lib.lib().ir2rgb_resample2d_bwd(_p(input1), _p(input2), _p(gradOutput), _p(gradInput1),
                                                   _p(gradInput2), N, C, H, W, kernel_size,
                                                   _lib.current_stream(input1))
@@ -113,7 +113,7 @@ class channelnorm_cuda:
         N, C, H, W = input1.shape
         if tuple(output.shape) != (N, 1, H, W):
             raise ValueError("channelnorm: output has the wrong shape")
-        with torch.cuda.device_of(input1):
+        with _lib.on_device(input1):
             rc = _lib.lib().ir2rgb_channelnorm_fwd(_p(input1), _p(output), N, C, H, W, norm_deg,
                                                    _lib.current_stream(input1))
         _lib.check(rc, "channelnorm_cuda.forward")
@@ -123,7 +123,7 @@ class channelnorm_cuda:
     def backward(input1, output, gradOutput, gradInput1, norm_deg):
         _lib.require_device(input1, output, gradOutput, gradInput1, dtype=_f32)
         N, C, H, W = input1.shape
-        with torch.cuda.device_of(input1):
+        with _lib.on_device(input1):
             rc = _lib.lib().ir2rgb_channelnorm_bwd(_p(input1), _p(output), _p(gradOutput), _p(gradInput1), N, C, H, W,
                                                    norm_deg, _lib.current_stream(input1))
         _lib.check(rc, "channelnorm_cuda.backward")
@@ -141,7 +141,7 @@ def warp_diff_norm(img1, img2, flow, want_warped=True, want_diff=True, want_norm
     diff = torch.empty_like(img2) if want_diff else None
     norm = img2.new_empty(N, 1, H, W) if want_norm else None
     null = ctypes.c_void_p(0)
-    with torch.cuda.device_of(img1):
+    with _lib.on_device(img1):
         rc = _lib.lib().ir2rgb_warp_diff_norm_fwd(_p(img1), _p(img2), _p(flow), _p(warped) if want_warped else null,
                                                   _p(diff) if want_diff else null, _p(norm) if want_norm else null,
                                                   N, C, H, W, _lib.current_stream(img1))

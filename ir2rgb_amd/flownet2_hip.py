@@ -104,7 +104,7 @@ def put_nchw(x_nchw, yv, act=0):
     """NCHW fp32 -> channel slice of an NHWC half buffer (optionally LeakyReLU(0.1))."""
     x = x_nchw.float().contiguous()
     n, c, h, w = x.shape
-    with torch.cuda.device_of(x):
+    with _lib.on_device(x):
         rc = _lib.lib().ir2rgb_nchw_f32_to_nhwc_half_slice(_p(x), _p(yv.buf), n, c, h, w, yv.ld, yv.off, act,
                                                            _DT[yv.buf.dtype], _lib.current_stream(x))
     _lib.check(rc, "nchw_f32_to_nhwc_half_slice")
@@ -113,7 +113,7 @@ def put_nchw(x_nchw, yv, act=0):
 def flow_up(flow, mod, yv):
     """ConvTranspose2d(2,2,4,2,1) of a 2-channel fp32 flow, written into a 2-channel slice of ``yv.buf``."""
     n, _, h, w = flow.shape
-    with torch.cuda.device_of(flow):
+    with _lib.on_device(flow):
         rc = _lib.lib().ir2rgb_flow_upsample_slice(_p(flow), _p(mod.weight), _p(mod.bias), _p(yv.buf), n, h, w, yv.ld, yv.off,
                                                    _DT[yv.buf.dtype], _lib.current_stream(flow))
     _lib.check(rc, "flow_upsample_slice")

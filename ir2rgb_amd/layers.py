@@ -65,7 +65,7 @@ def bn_finalize(stats, count, bn, training=True):
     invstd = torch.empty_like(scale)
     track = training and bn.track_running_stats and bn.running_mean is not None
     momentum = 0.1 if bn.momentum is None else bn.momentum
-    with torch.cuda.device_of(stats):
+    with _lib.on_device(stats):
         rc = _lib.lib().ir2rgb_bn_finalize(_p(stats), rows, ch, int(count), _p(bn.weight), _p(bn.bias),
                                            _p(bn.running_mean) if track else _p(None),
                                            _p(bn.running_var) if track else _p(None), float(momentum), float(bn.eps),
@@ -90,7 +90,7 @@ def flush_bn_counters():
 def bn_apply(x, scale, shift, act=ACT_NONE, res1=None, res2=None, out=None):
     n, ch, h, w = x.shape
     y = out if out is not None else torch.empty_like(x, memory_format=torch.channels_last)
-    with torch.cuda.device_of(x):
+    with _lib.on_device(x):
         rc = _lib.lib().ir2rgb_bn_apply(_p(x), _p(scale), _p(shift), _p(res1), _p(res2), _p(y), n * h * w, ch, act,
                                         _DT[x.dtype], _lib.current_stream(x))
     _lib.check(rc, "bn_apply")
@@ -108,7 +108,7 @@ def to_nhwc_half(x, dtype):
     x = x.float().contiguous()
     n, ch, h, w = x.shape
     y = C.empty_nhwc(n, ch, h, w, dtype, x.device)
-    with torch.cuda.device_of(x):
+    with _lib.on_device(x):
         rc = _lib.lib().ir2rgb_nchw_f32_to_nhwc_half(_p(x), _p(y), n, ch, h, w, _DT[dtype], _lib.current_stream(x))
     _lib.check(rc, "nchw_f32_to_nhwc_half")
     return y
@@ -122,7 +122,7 @@ def to_nchw_f32(x):
         return x.float().contiguous()
     n, ch, h, w = x.shape
     y = torch.empty((n, ch, h, w), dtype=torch.float32, device=x.device)
-    with torch.cuda.device_of(x):
+    with _lib.on_device(x):
         rc = _lib.lib().ir2rgb_nhwc_half_to_nchw_f32(_p(x), _p(y), n, ch, h, w, _DT[x.dtype], _lib.current_stream(x))
     _lib.check(rc, "nhwc_half_to_nchw_f32")
     return y
@@ -135,7 +135,7 @@ def xexpand(x, kw, stride_w, pad_w, pad_mode, dtype, cx=64):
     n, cin, h, w = x.shape
     wout = (w + 2 * pad_w - kw) // stride_w + 1
     y = C.empty_nhwc(n, cx, h, wout, dtype, x.device)
-    with torch.cuda.device_of(x):
+    with _lib.on_device(x):
         rc = _lib.lib().ir2rgb_xexpand_cx(_p(x), _p(y), n, cin, h, w, wout, kw, stride_w, pad_w, pad_mode, cx, _DT[dtype],
                                           _lib.current_stream(x))
     _lib.check(rc, "xexpand")
@@ -229,7 +229,7 @@ def head_stage(feat, convs, acts, mul=1.0):
     packed_acts = 0
     for i, a in enumerate(acts):
         packed_acts |= (a & 15) << (4 * i)
-    with torch.cuda.device_of(feat):
+    with _lib.on_device(feat):
         rc = _lib.lib().ir2rgb_head_finish(_p(t), _p(bias), _p(out), n, h, w, cout, kh, desc.Cout, kh // 2,
                                            packed_acts, float(mul), _lib.current_stream(feat))
     _lib.check(rc, "head_finish")
@@ -243,7 +243,7 @@ def warp_blend(raw, prev, flow, weight, want_warp=False):
     n, _, h, w = raw.shape
     out = torch.empty_like(raw)
     warp = torch.empty_like(raw) if want_warp else None
-    with torch.cuda.device_of(raw):
+    with _lib.on_device(raw):
         rc = _lib.lib().ir2rgb_warp_blend_fwd(_p(raw), _p(prev), _p(flow), _p(weight), _p(out), _p(warp), n,
                                               prev.shape[1], h, w, _lib.current_stream(raw))
     _lib.check(rc, "warp_blend_fwd")
