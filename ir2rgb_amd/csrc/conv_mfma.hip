@@ -107,8 +107,12 @@ __device__ __forceinline__ int reflect(int v, int n) {
 // gather offsets of this thread's pixel rows are precomputed for every tap (PROWS*NTY*NTX
 // registers), so a K-step's staging costs ~3 VALU per row.  NTY == 0: runtime tap grid (any
 // shape), offsets recomputed per K-step.
+// TP = 256: 3-stage LDS ring (144 KB, one workgroup per CU, 2 waves per SIMD) for long-K layers.
+// TP = 128: 2-stage ring (64 KB) and TP = 64: 3-stage ring (72 KB): two workgroups per CU (4 waves per
+// SIMD, <= 128 VGPRs), so one workgroup's prologue / epilogue / barrier stalls hide under the other's
+// MFMA work -- the configuration for short-K layers and for tile counts just above the CU count.
 template <int DT, int TP, int NTY, int NTX>
-__global__ void __launch_bounds__(512, 2)
+__global__ void __launch_bounds__(512, (TP == 256 ? 2 : 4))
 conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Wp, const float *__restrict__ bias,
                   uint16_t *__restrict__ Y, float *__restrict__ stats_partial, const ConvGeom g) {
     constexpr int TC = 128;
@@ -117,7 +121,8 @@ conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W
     constexpr int PROWS = TP / 64;         // pixel rows staged per thread per K-step
     constexpr int LOADS = WROWS + PROWS;   // LDS-DMA instructions per thread per K-step
     constexpr int STAGE = (TC + TP) * 128; // bytes per stage
-    constexpr int NSTAGE = 3;
+    constexpr int NSTAGE = TP == 128 ? 2 : 3;
+    constexpr int AHEAD = NSTAGE - 1;      // K-steps staged ahead of the one being multiplied
     constexpr bool STATIC_TAPS = NTY > 0;
     constexpr int NT = STATIC_TAPS ? NTY * NTX : 1;
     typedef Half<DT> H;
@@ -224,12 +229,12 @@ conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = g.kchunks * g.ntaps;
-    const bool late_dma = (g.variant & 1) && wave >= 4;  // wave-uniform (SGPR)
+    const bool late_dma = (g.variant & 1) && wave >= 4 && AHEAD >= 2;  // wave-uniform (SGPR)
 
     auto wait_stage = [&](int ks) {
-        // stage ks has landed for THIS wave once all but the newest LOADS (stage ks+1) are done
-        if (ks + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-        else             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // stage ks has landed for THIS wave once all but the newest LOADS*(AHEAD-1) (later stages) are done
+        if (AHEAD >= 2 && ks + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS * (AHEAD - 1)) : "memory");
+        else                           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // ... and for every wave; also: everyone is done reading stage ks-1
     };
     auto compute = [&](int buf) {
@@ -259,21 +264,21 @@ conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W
             for (int i = 0; i < PROWS; ++i) lds_dma16(rx, poff[i][t], (unsigned)cc * 128u, dst + TC * 128 + 8192 * i);
         };
         issue_static(0, 0, std::integral_constant<int, 0>{}, 0);
-        if (nk > 1) issue_static(1, NT > 1 ? 0 : 1, std::integral_constant<int, (NT > 1 ? 1 : 0)>{}, 1);
+        if (AHEAD >= 2 && nk > 1) issue_static(1, NT > 1 ? 0 : 1, std::integral_constant<int, (NT > 1 ? 1 : 0)>{}, 1);
         int ks = 0, buf = 0;
         for (int cc = 0; cc < g.kchunks; ++cc) {
             // unrolled over the taps: t is a compile-time constant inside
             auto body = [&](auto tconst) {
                 constexpr int t = decltype(tconst)::value;
                 wait_stage(ks);
-                constexpr int t2 = (t + 2) % NT;
-                const int cc2 = cc + (t + 2) / NT;
-                int b2 = buf + 2; b2 = b2 >= NSTAGE ? b2 - NSTAGE : b2;
+                constexpr int t2 = (t + AHEAD) % NT;
+                const int cc2 = cc + (t + AHEAD) / NT;
+                int b2 = buf + AHEAD; b2 = b2 >= NSTAGE ? b2 - NSTAGE : b2;
                 // SIMD partners (waves w, w+4) run complementary phases: the older half stages first and
                 // multiplies second, the younger half the other way round.
-                if (!late_dma && ks + 2 < nk) issue_static(ks + 2, cc2, std::integral_constant<int, t2>{}, b2);
+                if (!late_dma && ks + AHEAD < nk) issue_static(ks + AHEAD, cc2, std::integral_constant<int, t2>{}, b2);
                 compute(buf);
-                if (late_dma && ks + 2 < nk) issue_static(ks + 2, cc2, std::integral_constant<int, t2>{}, b2);
+                if (late_dma && ks + AHEAD < nk) issue_static(ks + AHEAD, cc2, std::integral_constant<int, t2>{}, b2);
                 ++ks;
                 buf = buf + 1 == NSTAGE ? 0 : buf + 1;
             };
@@ -282,14 +287,14 @@ conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W
         }
     } else {
         issue_dynamic(0, 0);
-        if (nk > 1) issue_dynamic(1, 1);
+        if (AHEAD >= 2 && nk > 1) issue_dynamic(1, 1);
         int buf = 0;
         for (int ks = 0; ks < nk; ++ks) {
             wait_stage(ks);
-            int b2 = buf + 2; b2 = b2 >= NSTAGE ? b2 - NSTAGE : b2;
-            if (!late_dma && ks + 2 < nk) issue_dynamic(ks + 2, b2);
+            int b2 = buf + AHEAD; b2 = b2 >= NSTAGE ? b2 - NSTAGE : b2;
+            if (!late_dma && ks + AHEAD < nk) issue_dynamic(ks + AHEAD, b2);
             compute(buf);
-            if (late_dma && ks + 2 < nk) issue_dynamic(ks + 2, b2);
+            if (late_dma && ks + AHEAD < nk) issue_dynamic(ks + AHEAD, b2);
             buf = buf + 1 == NSTAGE ? 0 : buf + 1;
         }
     }
@@ -297,7 +302,6 @@ conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W
     // ---------------- epilogue: bias, activation, BN statistics, NHWC store ----------------
     // acc[mi][ni][r]: cout = ct*TC + wc*64 + mi*16 + lq*4 + r ; pixel = pt*TP + wp*(TP/4) + ni*16 + l15
     __builtin_amdgcn_s_barrier();  // all waves are past their last LDS read: smem is reusable
-    float *red = reinterpret_cast<float *>(smem);  // [4 wp][TC][2]
     const int co_base = ct * TC + wc * 64 + lq * 4;
     long opix[NI];
     bool oval[NI];
@@ -310,6 +314,13 @@ conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W
         unsigned sy = rem / (unsigned)g.Wsub, sx = rem - sy * g.Wsub;
         opix[ni] = ((long)n * g.Hout + (sy * g.s_out_y + g.off_y)) * g.Wout + (sx * g.s_out_x + g.off_x);
     }
+    // Half outputs with Cout % 8 == 0 leave through LDS: each lane parks its 4-cout groups in a
+    // [TP pixels][128 couts] half tile (16-byte slot s of row r at s ^ (r & 15): conflict-free 8-byte
+    // writes), then the workgroup streams the tile out as 16-byte stores, 16 lanes per 256-byte pixel row
+    // -- full-line coalescing instead of 8-byte scattered stores.  `red` (BatchNorm partials) sits behind it.
+    const bool staged = !g.out_f32 && (g.Cout & 7) == 0 && (g.ldy & 7) == 0 && (g.co_off & 7) == 0;
+    unsigned char *otile = smem;                                   // TP * 256 B
+    float *red = reinterpret_cast<float *>(smem + TP * 256);       // [4 wp][TC][2]
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int co = co_base + mi * 16;
@@ -326,7 +337,14 @@ conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W
                 if (g.act) v[r] = v[r] > 0.f ? v[r] : (g.act == 1 ? 0.2f : 0.1f) * v[r];
                 if (oval[ni]) { s1[r] += v[r]; s2[r] += v[r] * v[r]; }
             }
-            if (oval[ni] && g.out_f32) {
+            if (staged) {
+                const int prow = wp * (TP / 4) + ni * 16 + l15;      // pixel row in the tile
+                const int cl = wc * 64 + mi * 16 + lq * 4;           // cout in the tile (multiple of 4)
+                uint2 pk;
+                pk.x = (uint32_t)H::cvt(v[0]) | ((uint32_t)H::cvt(v[1]) << 16);
+                pk.y = (uint32_t)H::cvt(v[2]) | ((uint32_t)H::cvt(v[3]) << 16);
+                *reinterpret_cast<uint2 *>(otile + prow * 256 + (((cl >> 3) ^ (prow & 15)) << 4) + (cl & 4) * 2) = pk;
+            } else if (oval[ni] && g.out_f32) {
                 float *dst = reinterpret_cast<float *>(Y) + opix[ni] * g.ldy + g.co_off + co;
                 if (co + 3 < g.Cout && (g.Cout & 3) == 0) {
                     *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
@@ -366,6 +384,24 @@ conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W
                     red[(wp * TC + cl) * 2 + 0] = s1[r];
                     red[(wp * TC + cl) * 2 + 1] = s2[r];
                 }
+            }
+        }
+    }
+    if (staged) {
+        __syncthreads();
+        // 512 threads: 16 lanes per pixel row, 32 rows per pass
+        const int c16 = tid & 15;
+        const bool cok = ct * TC + c16 * 8 < g.Cout;   // Cout % 8 == 0: a 16-byte chunk is all-in or all-out
+#pragma unroll
+        for (int pass = 0; pass < TP / 32; ++pass) {
+            const int prow = pass * 32 + (tid >> 4);
+            unsigned p = (unsigned)pt * TP + prow;
+            if (p < P && cok) {
+                unsigned n = p / HW, rem = p - n * HW;
+                unsigned sy = rem / (unsigned)g.Wsub, sx = rem - sy * g.Wsub;
+                long op = ((long)n * g.Hout + (sy * g.s_out_y + g.off_y)) * g.Wout + (sx * g.s_out_x + g.off_x);
+                const uint4 v = *reinterpret_cast<const uint4 *>(otile + prow * 256 + ((c16 ^ (prow & 15)) << 4));
+                *reinterpret_cast<uint4 *>(Y + op * g.ldy + g.co_off + ct * TC + c16 * 8) = v;
             }
         }
     }
@@ -431,10 +467,11 @@ static int conv_variant() {
     return v;
 }
 
-static int tile_pixels(long P, int Cout) {
-    // aim for >= 256 workgroups (one per CU); TP in {256, 128, 64}
+static int tile_pixels(long P, int Cout, int ksteps) {
+    // TP = 256 (one resident workgroup per CU) pays off for long K loops with at least one tile per CU;
+    // shorter loops / fewer tiles run two workgroups per CU with TP = 128 or 64.
     const long nct = (Cout + 127) / 128;
-    if (((P + 255) / 256) * nct >= 256) return 256;
+    if (((P + 255) / 256) * nct >= 256 && ksteps >= 40) return 256;
     if (((P + 127) / 128) * nct >= 256) return 128;
     return 64;
 }
@@ -524,7 +561,7 @@ static int make_plan(const ir2rgb_conv_desc *d, ClassPlan plans[4]) {
         if (xb >= (1L << 31) || wb >= (1L << 31)) return IR2RGB_EINVAL;  // 32-bit buffer offsets
         g.x_bytes = (unsigned)xb; g.w_bytes = (unsigned)wb;
         long P = (long)g.N * g.Hsub * g.Wsub;
-        int tp = tile_pixels(P, g.Cout);
+        int tp = tile_pixels(P, g.Cout, g.kchunks * g.ntaps);
         plans[i].npt = (int)((P + tp - 1) / tp);
         g.stats_row0 = row0;
         row0 += plans[i].npt;
@@ -594,7 +631,7 @@ static void launch_conv(const ClassPlan &c, const uint16_t *x, const uint16_t *w
                         float *stats, hipStream_t s) {
     const ConvGeom &g = c.geom;
     const long P = (long)g.N * g.Hsub * g.Wsub;
-    const int tp = tile_pixels(P, g.Cout);
+    const int tp = tile_pixels(P, g.Cout, g.kchunks * g.ntaps);
     const int nct = (g.Cout + 127) / 128;
     const unsigned grid = (unsigned)(c.npt * nct);
     const int nty = g.ntaps / g.ntx;
