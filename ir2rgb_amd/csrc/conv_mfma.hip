@@ -52,6 +52,7 @@ struct ConvGeom {
     int ldx, ci_off, ldy, co_off;  // channel-slice views: pixel stride (elements) and first channel of X / Y
     int stats_row0;           // first row of stats_partial written by this launch
     int out_f32;              // 1: Y is fp32 NHWC (head convolutions), 0: half
+    FastDiv div_hw, div_w;    // exact division by Hsub*Wsub and by Wsub
     unsigned x_bytes, w_bytes; // extents of X and of this class's packed weights (buffer resources, < 2^31)
     int variant;              // tuning switches (bit 0: waves 4-7 issue their LDS-DMA after their MFMA block)
     // taps form an nty x ntx grid: tap (ty,tx) reads input offset (dy0 + ty*dys, dx0 + tx*dxs).
@@ -167,8 +168,8 @@ conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W
         unsigned p = (unsigned)pt * TP + r8 + 64 * i;
         const bool v = p < P;
         p = v ? p : 0u;
-        unsigned n = p / HW, rem = p - n * HW;
-        unsigned sy = rem / (unsigned)g.Wsub;
+        unsigned n = fdiv(p, g.div_hw), rem = p - n * HW;
+        unsigned sy = fdiv(rem, g.div_w);
         // rows past the last pixel: zero padding -> parked outside the image (zero fill);
         // reflection -> pixel 0 (harmless, never stored)
         psy[i] = v ? (int)sy * g.s_in_y : (g.pad_mode ? 0 : -(1 << 20));
@@ -189,13 +190,33 @@ conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W
 
     unsigned poff[STATIC_TAPS ? PROWS : 1][NT];
     if constexpr (STATIC_TAPS) {
+        // the tap grid is separable: fold / range-check the NTY row and NTX column coordinates once per
+        // pixel row, then combine (NTY + NTX coordinate evaluations instead of NTY * NTX)
 #pragma unroll
-        for (int i = 0; i < PROWS; ++i)
+        for (int i = 0; i < PROWS; ++i) {
+            int ry[NTY > 0 ? NTY : 1], rx[NTX > 0 ? NTX : 1];  // row * Win, column; -1 = outside (zero padding)
+#pragma unroll
+            for (int ty = 0; ty < NTY; ++ty) {
+                int iy = psy[i] + g.dy0 + ty * g.dys;
+                const bool in = (unsigned)iy < (unsigned)g.Hin;
+                iy = g.pad_mode ? reflect(iy, g.Hin) : iy;
+                ry[ty] = (g.pad_mode || in) ? iy * g.Win : -1;
+            }
+#pragma unroll
+            for (int tx = 0; tx < NTX; ++tx) {
+                int ix = psx[i] + g.dx0 + tx * g.dxs;
+                const bool in = (unsigned)ix < (unsigned)g.Win;
+                ix = g.pad_mode ? reflect(ix, g.Win) : ix;
+                rx[tx] = (g.pad_mode || in) ? ix : -1;
+            }
+            const unsigned cbytes = (unsigned)(g.ci_off + chunk * 8) * 2u, ld2 = (unsigned)g.ldx * 2u;
 #pragma unroll
             for (int ty = 0; ty < NTY; ++ty)
 #pragma unroll
                 for (int tx = 0; tx < NTX; ++tx)
-                    poff[i][ty * NTX + tx] = gather_off(i, g.dy0 + ty * g.dys, g.dx0 + tx * g.dxs);
+                    poff[i][ty * NTX + tx] = ((ry[ty] | rx[tx]) < 0) ? IR2RGB_OOB
+                                                                      : (pbase[i] + (unsigned)(ry[ty] + rx[tx])) * ld2 + cbytes;
+        }
     }
 
     // runtime-tap path: running (chunk, tap-row, tap-col) of the next K-step to be issued
@@ -310,8 +331,8 @@ conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W
         unsigned p = (unsigned)pt * TP + wp * (TP / 4) + ni * 16 + l15;
         oval[ni] = p < P;
         p = oval[ni] ? p : 0u;
-        unsigned n = p / HW, rem = p - n * HW;
-        unsigned sy = rem / (unsigned)g.Wsub, sx = rem - sy * g.Wsub;
+        unsigned n = fdiv(p, g.div_hw), rem = p - n * HW;
+        unsigned sy = fdiv(rem, g.div_w), sx = rem - sy * g.Wsub;
         opix[ni] = ((long)n * g.Hout + (sy * g.s_out_y + g.off_y)) * g.Wout + (sx * g.s_out_x + g.off_x);
     }
     // Half outputs with Cout % 8 == 0 leave through LDS: each lane parks its 4-cout groups in a
@@ -371,11 +392,8 @@ conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W
             // sum over the 16 pixels held by lanes l15 = 0..15 of this quarter-wave
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int m = 1; m < 16; m <<= 1) {
-                    s1[r] += __shfl_xor(s1[r], m, 64);
-                    s2[r] += __shfl_xor(s2[r], m, 64);
-                }
+                s1[r] = row16_sum(s1[r]);
+                s2[r] = row16_sum(s2[r]);
             }
             if (l15 == 0) {
 #pragma unroll
@@ -397,8 +415,8 @@ conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W
             const int prow = pass * 32 + (tid >> 4);
             unsigned p = (unsigned)pt * TP + prow;
             if (p < P && cok) {
-                unsigned n = p / HW, rem = p - n * HW;
-                unsigned sy = rem / (unsigned)g.Wsub, sx = rem - sy * g.Wsub;
+                unsigned n = fdiv(p, g.div_hw), rem = p - n * HW;
+                unsigned sy = fdiv(rem, g.div_w), sx = rem - sy * g.Wsub;
                 long op = ((long)n * g.Hout + (sy * g.s_out_y + g.off_y)) * g.Wout + (sx * g.s_out_x + g.off_x);
                 const uint4 v = *reinterpret_cast<const uint4 *>(otile + prow * 256 + ((c16 ^ (prow & 15)) << 4));
                 *reinterpret_cast<uint4 *>(Y + op * g.ldy + g.co_off + ct * TC + c16 * 8) = v;
@@ -471,7 +489,9 @@ static int tile_pixels(long P, int Cout, int ksteps) {
     // TP = 256 (one resident workgroup per CU) pays off for long K loops with at least one tile per CU;
     // shorter loops / fewer tiles run two workgroups per CU with TP = 128 or 64.
     const long nct = (Cout + 127) / 128;
-    if (((P + 255) / 256) * nct >= 256 && ksteps >= 40) return 256;
+    const long tiles256 = ((P + 255) / 256) * nct;
+    // long K loops, or many tiles of a large (HBM-streaming) input: the deep 3-stage ring wins
+    if (tiles256 >= 256 && (ksteps >= 40 || tiles256 >= 768)) return 256;
     if (((P + 127) / 128) * nct >= 256) return 128;
     return 64;
 }
@@ -551,6 +571,7 @@ static int make_plan(const ir2rgb_conv_desc *d, ClassPlan plans[4]) {
     for (int i = 0; i < ncls; ++i) {
         ConvGeom &g = plans[i].geom;
         g.variant = conv_variant();
+        g.div_hw = make_fastdiv((unsigned)(g.Hsub * g.Wsub)); g.div_w = make_fastdiv((unsigned)g.Wsub);
         g.ldx = d->ldx > 0 ? d->ldx : d->Cin; g.ci_off = d->ci_off;
         g.ldy = d->ldy > 0 ? d->ldy : d->Cout; g.co_off = d->co_off;
         if (g.ci_off < 0 || g.co_off < 0 || g.ci_off + d->Cin > g.ldx || g.co_off + d->Cout > g.ldy || (g.ldx & 7) || (g.ci_off & 7))

@@ -35,15 +35,21 @@ struct WgradGeom {
     int nty, ntx, dy0, dx0; // tap (ty,tx): V coordinate = q*stride + (dy0+ty, dx0+tx)
     int ksplit, ksteps;     // K-steps (64 pixels each) in total and number of splits
     int use_atomics;
+    FastDiv div_hw, div_w;  // exact division by Hq*Wq and by Wq
+    unsigned u_bytes, v_bytes;  // extents of U and V (buffer resources, < 2^31)
 };
 
-__device__ __attribute__((aligned(256))) uint4 g_wgrad_zero_page[16];  // 256 B of zeros
-
-typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+#define WG_OOB 0x80000000u  // per-lane offset past any extent: the LDS-DMA delivers zeros
 
-__device__ __forceinline__ void dma16(const void *src, unsigned char *dst_wave_base) {
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst_wave_base, 16, 0, 0);
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+// buffer-addressed LDS-DMA: 16 B per lane from base + 32-bit per-lane byte offset (range-checked, zeros
+// when out of range) to LDS at wave-uniform base + lane * 16
+__device__ __forceinline__ void dma16(rsrc_t r, unsigned voff, unsigned char *dst_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr_t)dst_wave_base, 16, voff, 0, 0, 0);
 }
 
 __device__ __forceinline__ int reflect1(int v, int n) {
@@ -95,28 +101,42 @@ conv_wgrad_kernel(const uint16_t *__restrict__ U, const uint16_t *__restrict__ V
     const int f = (r0 & 3) | (((r0 >> 3) & 1) << 2);            // same for r0 + 16*i
     const int chunk = ((((slot >> 1) ^ f) << 1) | (slot & 1));  // source 16-B chunk held by this LDS slot
     const bool a_ok = a0 + chunk * 8 < g.Ca, b_ok = b0 + chunk * 8 < g.Cb;
-    const uint16_t *zsrc = reinterpret_cast<const uint16_t *>(g_wgrad_zero_page) + slot * 8;
-    const uint16_t *usrc = U + a0 + chunk * 8;
-    const uint16_t *vsrc = V + b0 + chunk * 8;
+    const rsrc_t ru = make_rsrc(U, g.u_bytes), rv = make_rsrc(V, g.v_bytes);
+    const unsigned ubase = a_ok ? (unsigned)(a0 + chunk * 8) * 2u : WG_OOB;  // byte offset inside a pixel row
+    const unsigned vbase = b_ok ? (unsigned)(b0 + chunk * 8) * 2u : WG_OOB;
     const unsigned Q = (unsigned)g.N * g.Hq * g.Wq, HWq = (unsigned)g.Hq * g.Wq;
+    const unsigned ca2 = (unsigned)g.Ca * 2u, cb2 = (unsigned)g.Cb * 2u;
     unsigned char *const wave_dst = smem + wave * 1024;  // + buf*STAGE + 4096*i (+16384 for V)
+    const bool wide = g.Wq >= 16;  // rows r0+16*i of one K-step then wrap at most once per step of 16
 
     auto issue = [&](int ks, int buf) {
         unsigned char *dst = wave_dst + buf * STAGE;
+        // pixel coordinates of this thread's first row by exact division, the other three incrementally
+        unsigned q = (unsigned)ks * 64u + r0;
+        unsigned qq = q < Q ? q : 0u;
+        unsigned n = fdiv(qq, g.div_hw), rem = qq - n * HWq;
+        unsigned qy = fdiv(rem, g.div_w), qx = rem - qy * g.Wq;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            unsigned q = (unsigned)ks * 64u + r0 + 16 * i;
             const bool v = q < Q;
-            q = v ? q : 0u;
-            const unsigned n = q / HWq, rem = q - n * HWq;
-            const unsigned qy = rem / (unsigned)g.Wq, qx = rem - qy * g.Wq;
-            dma16((v && a_ok) ? usrc + (unsigned long)q * g.Ca : zsrc, dst + 4096 * i);
+            dma16(ru, v ? ubase + q * ca2 : WG_OOB, dst + 4096 * i);
             int iy = (int)qy * g.stride_y + dy, ix = (int)qx * g.stride_x + dx;
             const bool inb = ((unsigned)iy < (unsigned)g.Hv) & ((unsigned)ix < (unsigned)g.Wv);
             iy = g.pad_mode ? reflect1(iy, g.Hv) : iy;
             ix = g.pad_mode ? reflect1(ix, g.Wv) : ix;
-            const unsigned long vp = ((unsigned long)n * g.Hv + iy) * g.Wv + ix;
-            dma16((v && b_ok && (g.pad_mode || inb)) ? vsrc + vp * g.Cb : zsrc, dst + 16384 + 4096 * i);
+            const unsigned vp = (n * (unsigned)g.Hv + (unsigned)iy) * (unsigned)g.Wv + (unsigned)ix;
+            dma16(rv, (v && (g.pad_mode || inb)) ? vbase + vp * cb2 : WG_OOB, dst + 16384 + 4096 * i);
+            if (i < 3) {
+                q += 16;
+                if (wide) {
+                    qx += 16;
+                    if (qx >= (unsigned)g.Wq) { qx -= g.Wq; if (++qy >= (unsigned)g.Hq) { qy = 0; ++n; } }
+                } else {
+                    qq = q < Q ? q : 0u;
+                    n = fdiv(qq, g.div_hw); rem = qq - n * HWq;
+                    qy = fdiv(rem, g.div_w); qx = rem - qy * g.Wq;
+                }
+            }
         }
     };
 
@@ -225,6 +245,12 @@ static int plan(const ir2rgb_conv_desc *d, WgradGeom *g) {
     if (ks < 1) ks = 1;
     g->ksplit = ks;
     g->use_atomics = ks > 1;
+    g->div_hw = make_fastdiv((unsigned)(g->Hq * g->Wq)); g->div_w = make_fastdiv((unsigned)g->Wq);
+    {
+        const long ub = Q * g->Ca * 2, vb = (long)g->N * g->Hv * g->Wv * g->Cb * 2;
+        if (ub >= (1L << 31) || vb >= (1L << 31)) return IR2RGB_EINVAL;  // 32-bit buffer offsets
+        g->u_bytes = (unsigned)ub; g->v_bytes = (unsigned)vb;
+    }
     return IR2RGB_OK;
 }
 

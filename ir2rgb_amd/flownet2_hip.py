@@ -53,7 +53,40 @@ class View:
         return self.buf.shape[2], self.buf.shape[3]
 
 
+class Workspace:
+    """Per-(sub-network, input shape) pool of NHWC buffers, allocated and zero-filled once.  Buffers are
+    handed out in call order; pad channels are never written, so they stay zero across calls, and every
+    real channel is overwritten by its producer on each forward."""
+    _pools = {}
+    _current = None
+
+    def __init__(self):
+        self.bufs, self.cursor = [], 0
+
+    @classmethod
+    def activate(cls, key):
+        ws = cls._pools.get(key)
+        if ws is None:
+            ws = cls._pools[key] = Workspace()
+        ws.cursor = 0
+        cls._current = ws
+        return ws
+
+    def take(self, shape, dtype, device):
+        if self.cursor < len(self.bufs):
+            b = self.bufs[self.cursor]
+            if tuple(b.shape) != tuple(shape) or b.dtype != dtype or b.device != device:
+                raise RuntimeError("FlowNet2 workspace: allocation sequence changed")
+        else:
+            b = torch.zeros(shape, dtype=dtype, device=device).contiguous(memory_format=torch.channels_last)
+            self.bufs.append(b)
+        self.cursor += 1
+        return b
+
+
 def new_buf(n, ld, h, w, dtype, device):
+    if Workspace._current is not None:
+        return Workspace._current.take((n, ld, h, w), dtype, device)
     return torch.zeros((n, ld, h, w), dtype=dtype, device=device).contiguous(memory_format=torch.channels_last)
 
 
@@ -171,6 +204,7 @@ def _dense(n, ch, h, w, dtype, device):
 
 def flownetc(net, x, dtype):
     """x [N,6,H,W] fp32 (two normalised images) -> flow2 [N,2,H/4,W/4] fp32 (reference FlowNetC.py:75-126)."""
+    Workspace.activate((id(net), tuple(x.shape), dtype, x.device))
     n, _, H, W = x.shape
     dev = x.device
     dec = _Decoder(n, H // 64, W // 64, dtype, dev)
@@ -194,6 +228,7 @@ def flownetc(net, x, dtype):
 
 def flownets(net, x, dtype):
     """x [N,12,H,W] fp32 -> flow2 (reference FlowNetS.py:57-93)."""
+    Workspace.activate((id(net), tuple(x.shape), dtype, x.device))
     n, _, H, W = x.shape
     dev = x.device
     dec = _Decoder(n, H // 64, W // 64, dtype, dev)
@@ -209,6 +244,7 @@ def flownets(net, x, dtype):
 
 def flownetsd(net, x, dtype):
     """x [N,6,H,W] fp32 -> flow2 (reference FlowNetSD.py:66-105)."""
+    Workspace.activate((id(net), tuple(x.shape), dtype, x.device))
     n, _, H, W = x.shape
     dev = x.device
     dec = _Decoder(n, H // 64, W // 64, dtype, dev)
@@ -226,6 +262,7 @@ def flownetsd(net, x, dtype):
 
 def flownetfusion(net, x, dtype):
     """x [N,11,H,W] fp32 -> flow0 [N,2,H,W] (reference FlowNetFusion.py:47-66)."""
+    Workspace.activate((id(net), tuple(x.shape), dtype, x.device))
     n, _, H, W = x.shape
     dev = x.device
     cat0 = new_buf(n, 128, H, W, dtype, dev)            # [conv0 64 | deconv0 16 | flow1_up 2 | pad]

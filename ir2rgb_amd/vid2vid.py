@@ -244,7 +244,7 @@ class Vid2VidTrainer:
             fw, dw = 4.0 / (o["n_layers_D"] + 1), 1.0 / o["num_D"]
             for i in range(min(len(pred_fake), o["num_D"])):
                 for j in range(len(pred_fake[i]) - 1):
-                    loss_fm = loss_fm + dw * fw * F.l1_loss(pred_fake[i][j].float(), pred_real[i][j].detach().float()) * o["lambda_feat"]
+                    loss_fm = loss_fm + dw * fw * (pred_fake[i][j] - pred_real[i][j].detach()).abs().mean(dtype=torch.float32) * o["lambda_feat"]
         return loss_gan, loss_fm
 
     def _loss_D(self, netD, real_in, fake_in):
