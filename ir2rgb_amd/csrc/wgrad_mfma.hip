@@ -16,9 +16,10 @@
 // (two 16-lane groups x 4 rows) hit 8 disjoint 32-byte bank windows.
 //
 // Workgroup = 256 threads (4 waves, 2x2), tile 128 (a) x 128 (b) for ONE tap and one K-split,
-// K-step = 64 pixels, two LDS stages (64 KB -> 2 workgroups per CU).  Split-K partial tiles are
-// combined with fp32 atomics into a zeroed [tap][a][b] buffer; wgrad_finish permutes it into the
-// torch weight layout.  Algorithmic flops = 2 * Q * Ca * Cb * ntaps; bound: MFMA.
+// K-step = 64 pixels, two LDS stages (64 KB -> 2 workgroups per CU).  Split-K partial tiles go to
+// per-split fp32 slabs [split][tap][a][b] with plain stores (no float atomics: they run at ~1.3 TB/s
+// chip-wide and are order-dependent); wgrad_finish sums the slabs and permutes into the torch weight
+// layout -- deterministic.  Algorithmic flops = 2 * Q * Ca * Cb * ntaps; bound: MFMA.
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -83,8 +84,13 @@ conv_wgrad_kernel(const uint16_t *__restrict__ U, const uint16_t *__restrict__ V
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nta = (g.Ca + 127) >> 7, ntb = (g.Cb + 127) >> 7;
-    // blockIdx.x -> (split, tap, tile_a, tile_b); splits of one tile are far apart in block id
-    int bid = blockIdx.x;
+    // XCD-aware bijective remap (blocks b, b+8, ... share an L2): each XCD gets a contiguous run of
+    // (split, tap, tile_a, tile_b) ids, i.e. few distinct U / V panels per private L2.
+    int bid;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
     const int tb = bid % ntb; bid /= ntb;
     const int ta = bid % nta; bid /= nta;
     const int tap = bid % (g.nty * g.ntx);
@@ -109,33 +115,45 @@ conv_wgrad_kernel(const uint16_t *__restrict__ U, const uint16_t *__restrict__ V
     unsigned char *const wave_dst = smem + wave * 1024;  // + buf*STAGE + 4096*i (+16384 for V)
     const bool wide = g.Wq >= 16;  // rows r0+16*i of one K-step then wrap at most once per step of 16
 
+    // one DMA pair (U row, gathered V row) for pixel q = (n, qy, qx); all selects, no branches
+    auto issue_row = [&](unsigned q, unsigned n, unsigned qy, unsigned qx, unsigned char *dst) {
+        const bool v = q < Q;
+        dma16(ru, v ? ubase + q * ca2 : WG_OOB, dst);
+        int iy = (int)qy * g.stride_y + dy, ix = (int)qx * g.stride_x + dx;
+        const bool inb = ((unsigned)iy < (unsigned)g.Hv) & ((unsigned)ix < (unsigned)g.Wv);
+        iy = g.pad_mode ? reflect1(iy, g.Hv) : iy;
+        ix = g.pad_mode ? reflect1(ix, g.Wv) : ix;
+        const unsigned vp = (n * (unsigned)g.Hv + (unsigned)iy) * (unsigned)g.Wv + (unsigned)ix;
+        dma16(rv, (v && (g.pad_mode || inb)) ? vbase + vp * cb2 : WG_OOB, dst + 16384);
+    };
     auto issue = [&](int ks, int buf) {
         unsigned char *dst = wave_dst + buf * STAGE;
-        // pixel coordinates of this thread's first row by exact division, the other three incrementally
+        // pixel coordinates of this thread's first row by exact division ...
         unsigned q = (unsigned)ks * 64u + r0;
         unsigned qq = q < Q ? q : 0u;
         unsigned n = fdiv(qq, g.div_hw), rem = qq - n * HWq;
         unsigned qy = fdiv(rem, g.div_w), qx = rem - qy * g.Wq;
+        if (wide) {  // ... the other three incrementally (a step of 16 pixels wraps at most one image row)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool v = q < Q;
-            dma16(ru, v ? ubase + q * ca2 : WG_OOB, dst + 4096 * i);
-            int iy = (int)qy * g.stride_y + dy, ix = (int)qx * g.stride_x + dx;
-            const bool inb = ((unsigned)iy < (unsigned)g.Hv) & ((unsigned)ix < (unsigned)g.Wv);
-            iy = g.pad_mode ? reflect1(iy, g.Hv) : iy;
-            ix = g.pad_mode ? reflect1(ix, g.Wv) : ix;
-            const unsigned vp = (n * (unsigned)g.Hv + (unsigned)iy) * (unsigned)g.Wv + (unsigned)ix;
-            dma16(rv, (v && (g.pad_mode || inb)) ? vbase + vp * cb2 : WG_OOB, dst + 16384 + 4096 * i);
-            if (i < 3) {
+            for (int i = 0; i < 4; ++i) {
+                issue_row(q, n, qy, qx, dst + 4096 * i);
                 q += 16;
-                if (wide) {
-                    qx += 16;
-                    if (qx >= (unsigned)g.Wq) { qx -= g.Wq; if (++qy >= (unsigned)g.Hq) { qy = 0; ++n; } }
-                } else {
-                    qq = q < Q ? q : 0u;
-                    n = fdiv(qq, g.div_hw); rem = qq - n * HWq;
-                    qy = fdiv(rem, g.div_w); qx = rem - qy * g.Wq;
-                }
+                qx += 16;
+                const bool wr_ = qx >= (unsigned)g.Wq;
+                qx = wr_ ? qx - g.Wq : qx;
+                qy += wr_ ? 1u : 0u;
+                const bool wy_ = qy >= (unsigned)g.Hq;
+                qy = wy_ ? 0u : qy;
+                n += wy_ ? 1u : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                issue_row(q, n, qy, qx, dst + 4096 * i);
+                q += 16;
+                qq = q < Q ? q : 0u;
+                n = fdiv(qq, g.div_hw); rem = qq - n * HWq;
+                qy = fdiv(rem, g.div_w); qx = rem - qy * g.Wq;
             }
         }
     };
@@ -144,22 +162,22 @@ conv_wgrad_kernel(const uint16_t *__restrict__ U, const uint16_t *__restrict__ V
     const int wr = wave >> 1, wc = wave & 1;       // wave tile: rows a = wr*64.., cols b = wc*64..
     const int grp = lane >> 4, l15 = lane & 15;
     const int qd = l15 >> 2, pp = l15 & 3;          // transposed read: lane 4q+p -> LDS row q, channels 4p..4p+3
-    // pixel row of this lane's address within a K32 step: 8*grp + 4*h + qd  (h = 0,1)
-    // channel = tile_col0 + 16*m + 4*pp -> pair = (col0/16 + m), chunk-in-pair = pp >> 1, byte-in-chunk = (pp & 1) * 8
-    auto frag = [&](const unsigned char *tile, int col0, int kk) -> s16x8 {
-        s16x4 lo, hi;
-        {
-            const int r = kk * 32 + 8 * grp + qd;
-            const int fr = (r & 3) | (((r >> 3) & 1) << 2);
-            const int pair = (col0 >> 4) ^ fr;
-            lo = lds_tr(tile + r * 256 + pair * 32 + (pp >> 1) * 16 + (pp & 1) * 8);
-        }
-        {
-            const int r = kk * 32 + 8 * grp + 4 + qd;
-            const int fr = (r & 3) | (((r >> 3) & 1) << 2);
-            const int pair = (col0 >> 4) ^ fr;
-            hi = lds_tr(tile + r * 256 + pair * 32 + (pp >> 1) * 16 + (pp & 1) * 8);
-        }
+    // Row read by this lane in K32-step kk, half h: r = kk*32 + 4*h + (8*grp + qd).  Its swizzle term
+    // f(r) = (r&3) | ((r>>3)&1)<<2 = qd | (grp&1)<<2 does not depend on (kk, h): a per-lane constant.  So
+    //   address = [ (8*grp+qd)*256 + (pp>>1)*16 + (pp&1)*8 + ((col0>>4) ^ fr)*32 ]   per lane and per m
+    //           + (kk*32 + 4*h)*256                                                  instruction immediate
+    //           + tile base                                                          one add per K-step and m
+    const int fr = qd | ((grp & 1) << 2);
+    const int lane_off = (8 * grp + qd) * 256 + (pp >> 1) * 16 + (pp & 1) * 8;
+    int aoff[4], boff[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        aoff[m] = lane_off + ((((wr * 64 + m * 16) >> 4) ^ fr) << 5);
+        boff[m] = lane_off + ((((wc * 64 + m * 16) >> 4) ^ fr) << 5) + 16384;
+    }
+    auto frag = [&](const unsigned char *p, int kk) -> s16x8 {
+        const s16x4 lo = lds_tr(p + (kk * 32) * 256);
+        const s16x4 hi = lds_tr(p + (kk * 32 + 4) * 256);
         return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     };
 
@@ -175,14 +193,17 @@ conv_wgrad_kernel(const uint16_t *__restrict__ U, const uint16_t *__restrict__ V
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (ks + 1 < kend) issue(ks + 1, buf ^ 1);
-        const unsigned char *tu = smem + buf * STAGE, *tv = tu + 16384;
+        const unsigned char *tile = smem + buf * STAGE;
+        const unsigned char *pa[4], *pb[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { pa[m] = tile + aoff[m]; pb[m] = tile + boff[m]; }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             s16x8 a[4], b[4];
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) a[mi] = frag(tu, wr * 64 + mi * 16, kk);
+            for (int mi = 0; mi < 4; ++mi) a[mi] = frag(pa[mi], kk);
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) b[ni] = frag(tv, wc * 64 + ni * 16, kk);
+            for (int ni = 0; ni < 4; ++ni) b[ni] = frag(pb[ni], kk);
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -191,8 +212,8 @@ conv_wgrad_kernel(const uint16_t *__restrict__ U, const uint16_t *__restrict__ V
         buf ^= 1;
     }
 
-    // ---------------- epilogue: D[tap][a][b] (fp32) ----------------
-    float *Dt = D + (long)tap * g.Ca * g.Cb;
+    // ---------------- epilogue: D[split][tap][a][b] (fp32 slab of this K-split) ----------------
+    float *Dt = D + ((long)split * (g.nty * g.ntx) + tap) * g.Ca * g.Cb;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -202,21 +223,24 @@ conv_wgrad_kernel(const uint16_t *__restrict__ U, const uint16_t *__restrict__ V
             for (int r = 0; r < 4; ++r) {
                 const int a = a0 + wr * 64 + mi * 16 + grp * 4 + r;
                 if (a < g.Ca && b < g.Cb) {
-                    float *dst = Dt + (long)a * g.Cb + b;
-                    if (g.use_atomics) atomicAdd(dst, acc[mi][ni][r]);
-                    else *dst = acc[mi][ni][r];
+                    Dt[(long)a * g.Cb + b] = acc[mi][ni][r];
                 }
             }
         }
 }
 
-// out[a][b][tap] = D[tap][a][b]   (torch weight layout [Ca][Cb][kh][kw], fp32)
+// out[a][b][tap] = sum_split D[split][tap][a][b]   (torch weight layout [Ca][Cb][kh][kw], fp32)
 __global__ void __launch_bounds__(256)
-wgrad_finish_kernel(const float *__restrict__ D, float *__restrict__ out, int Ca, int Cb, int ntaps, long total) {
+wgrad_finish_kernel(const float *__restrict__ D, float *__restrict__ out, int Ca, int Cb, int ntaps, int nsplit,
+                    long total) {
+    const long slab = (long)ntaps * Ca * Cb;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int tap = (int)(i % ntaps);
         const long ab = i / ntaps;
-        out[i] = D[(long)tap * Ca * Cb + ab];
+        const float *p = D + (long)tap * Ca * Cb + ab;
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += p[k * slab];
+        out[i] = s;
     }
 }
 
@@ -238,13 +262,20 @@ static int plan(const ir2rgb_conv_desc *d, WgradGeom *g) {
     long Q = (long)g->N * g->Hq * g->Wq;
     if (Q >= (1L << 31) || (long)g->N * g->Hv * g->Wv >= (1L << 31)) return IR2RGB_EINVAL;
     g->ksteps = (int)((Q + 63) / 64);
-    long tiles = (long)d->kh * d->kw * ((g->Ca + 127) / 128) * ((g->Cb + 127) / 128);
-    int ks = (int)((768 + tiles - 1) / tiles);           // aim for ~3 workgroups per CU
-    int maxsplit = g->ksteps / 4 > 0 ? g->ksteps / 4 : 1;  // at least 4 K-steps per split
-    if (ks > maxsplit) ks = maxsplit;
-    if (ks < 1) ks = 1;
-    g->ksplit = ks;
-    g->use_atomics = ks > 1;
+    // K-split by a cost model: rounds of 512 resident workgroups (2 per CU) x (K-steps per split + pipeline
+    // fill) against the extra slab traffic of the finish pass (split x elems x 8 bytes at ~4 TB/s).
+    const long tiles = (long)d->kh * d->kw * ((g->Ca + 127) / 128) * ((g->Cb + 127) / 128);
+    const double elems = (double)d->kh * d->kw * g->Ca * g->Cb;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int ks = 1; ks <= 64; ++ks) {
+        if (ks > 1 && g->ksteps / ks < 4) break;               // at least 4 K-steps per split
+        const double rounds = (double)((tiles * ks + 511) / 512);
+        const double cost = rounds * ((g->ksteps + ks - 1) / ks + 3) * 1.2 + ks * elems * 8.0 / 4e6;  // microseconds
+        if (cost < best_cost) { best_cost = cost; best = ks; }
+    }
+    g->ksplit = best;
+    g->use_atomics = 0;
     g->div_hw = make_fastdiv((unsigned)(g->Hq * g->Wq)); g->div_w = make_fastdiv((unsigned)g->Wq);
     {
         const long ub = Q * g->Ca * 2, vb = (long)g->N * g->Hv * g->Wv * g->Cb * 2;
@@ -258,7 +289,7 @@ extern "C" long ir2rgb_conv2d_wgrad_workspace_elems(const ir2rgb_conv_desc *d) {
     WgradGeom g;
     int rc = plan(d, &g);
     if (rc) return rc;
-    return (long)d->kh * d->kw * g.Ca * g.Cb;
+    return (long)g.ksplit * d->kh * d->kw * g.Ca * g.Cb;
 }
 
 extern "C" int ir2rgb_conv2d_wgrad(const ir2rgb_conv_desc *d, const void *x, const void *gy, float *dw,
@@ -270,14 +301,10 @@ extern "C" int ir2rgb_conv2d_wgrad(const ir2rgb_conv_desc *d, const void *x, con
     hipStream_t s = as_stream(stream);
     const int ntaps = d->kh * d->kw;
     const long elems = (long)ntaps * g.Ca * g.Cb;
-    if (g.use_atomics) {
-        hipError_t e = hipMemsetAsync(workspace, 0, sizeof(float) * (size_t)elems, s);
-        if (e != hipSuccess) return (int)e;
-    }
     const uint16_t *U = (const uint16_t *)(d->transposed ? x : gy), *V = (const uint16_t *)(d->transposed ? gy : x);
     const unsigned grid = (unsigned)((long)g.ksplit * ntaps * ((g.Ca + 127) / 128) * ((g.Cb + 127) / 128));
     if (d->dtype == IR2RGB_BF16) conv_wgrad_kernel<IR2RGB_BF16><<<grid, 256, 0, s>>>(U, V, workspace, g);
     else conv_wgrad_kernel<IR2RGB_F16><<<grid, 256, 0, s>>>(U, V, workspace, g);
-    wgrad_finish_kernel<<<stream_grid(elems, 256), 256, 0, s>>>(workspace, dw, g.Ca, g.Cb, ntaps, elems);
+    wgrad_finish_kernel<<<stream_grid(elems, 256), 256, 0, s>>>(workspace, dw, g.Ca, g.Cb, ntaps, g.ksplit, elems);
     return ir2rgb_launch_status();
 }

@@ -84,6 +84,14 @@ int oracle_correlation_fwd(const float *in1, const float *in2, float *out, int N
                         double acc = 0.0;
                         for (int j = -krad; j <= krad; ++j)
                             for (int i = -krad; i <= krad; ++i) {
+                                /* For kernel_size > 1 the reference indexes the padded buffers at
+                                 * y2 + j = max_disp - drad*stride2 - krad, which is negative whenever
+                                 * pad <= that reach: undefined behaviour in the reference (an out-of-
+                                 * bounds global read).  Positions outside the padded frame count as
+                                 * zeros here, which is also what the HIP kernel does. */
+                                if (y1 + j < 0 || y1 + j >= pH || x1 + i < 0 || x1 + i >= pW || y2 + j < 0 ||
+                                    y2 + j >= pH || x2 + i < 0 || x2 + i >= pW)
+                                    continue;
                                 const float *p1 = r1 + (((size_t)n * pH + (y1 + j)) * pW + (x1 + i)) * C;
                                 const float *p2 = r2 + (((size_t)n * pH + (y2 + j)) * pW + (x2 + i)) * C;
                                 for (int c = 0; c < C; ++c) acc += (double)(p1[c] * p2[c]);
