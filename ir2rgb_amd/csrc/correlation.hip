@@ -8,13 +8,14 @@
 // This design (forward fast path, the FlowNetC configuration k=1, stride1=1, pad=max_disp):
 //   * reads the NCHW inputs directly; zero padding is a predicate on 16-byte loads, so the
 //     algorithmic traffic is 2 inputs + 1 output and no scratch tensor exists;
-//   * one 64-lane WAVE owns (n, y, tj, 128-wide x chunk): 16 lanes tile x in runs of 8 pixels,
-//     the 4 lane-quarters split the channels.  A lane keeps a (2*DR+1) x 8 register tile of
-//     partial dot products (168 accumulators for DR=10): per channel it loads 8 floats of f1
-//     and 8+2*S2*DR floats of f2 as float4s and issues 168 FMAs (3 FMA per loaded dword);
-//   * the 4 channel quarters are combined with two wave64 xor-shuffles (lanes^16, ^32) --
-//     the only cross-lane step; every lane then stores its share of the 21 rows as 32-byte
-//     runs (512 B contiguous per row per wave).
+//   * one WORKGROUP owns (n, y, tj, 128-wide x chunk); its 4 waves split the 21 x-displacements in
+//     two halves and the channels in two halves.  In a wave 16 lanes tile x in runs of 8 pixels and
+//     the 4 lane-quarters interleave the channels; a lane keeps a (<=12) x 8 register tile of partial
+//     dot products: per channel it loads 8 floats of f1 and <=30 floats of f2 as float4s and issues
+//     up to 96 FMAs (2.5 FMA per loaded dword) at ~160 VGPRs (3 waves per SIMD);
+//   * the lane quarters are combined with two wave64 xor-shuffles (lanes^16, ^32), the channel
+//     halves through LDS; every lane quarter then stores its share of the rows as 32-byte runs
+//     (512 B contiguous per row per wave).
 // A generic one-lane-per-output kernel covers every other parameter set.
 //
 // Algorithmic bytes (forward) = 4*N*(2*C*H*W + outC*outH*outW); flops = 2*N*outC*outH*outW*k*k*C.
@@ -40,88 +41,109 @@ extern "C" int ir2rgb_correlation_out_shape(int C, int H, int W, int pad_size, i
 
 // ----------------------------------------------------------------------------------------
 // fast forward path
+//   workgroup (256 threads) = one unit (n, y, tj, 128-wide x chunk); its 4 waves split the unit into
+//   2 displacement halves (ti 0..T0-1 and T0..D-1; T0 = 12 keeps both f2 windows float4 aligned) x
+//   2 channel halves.  Within a wave: 16 lanes tile x in runs of 8 pixels, the 4 lane-quarters
+//   interleave the wave's channels.  A lane keeps a (<= 12) x 8 register tile of partial dot
+//   products (<= 96 accumulators, ~160 VGPRs -> 3 waves per SIMD): 4x the waves in flight of a
+//   one-wave-per-unit layout, which is what hides the L2/HBM latency of the operand loads.
+//   Reduction: two wave64 xor-shuffles combine the lane quarters, the channel halves meet in LDS.
 // ----------------------------------------------------------------------------------------
-template <int DR, int S2>
+template <int DR, int S2, int T0>
 __global__ void __launch_bounds__(256)
 corr_fwd_tile(const float *__restrict__ f1, const float *__restrict__ f2, float *__restrict__ out, int C, int H,
-              int W, int xchunks, long units, float inv_nelems) {
+              int W, int xchunks, float inv_nelems) {
     constexpr int D = 2 * DR + 1;
-    constexpr int HALO = S2 * DR;       // floats left/right of the 8-pixel run
-    constexpr int NB = 8 + 2 * HALO;    // f2 floats needed per lane per channel
-    static_assert(HALO % 4 == 0, "halo must keep float4 alignment");
-    constexpr int NB4 = NB / 4;
+    constexpr int TMAX = T0 > D - T0 ? T0 : D - T0;  // displacements per wave (first half is the larger)
+    constexpr int HALO = S2 * DR;
+    constexpr int NB = 8 + S2 * (TMAX - 1);           // f2 floats needed per lane per channel
+    constexpr int NB4 = (NB + 3) / 4;
+    static_assert(HALO % 4 == 0 && (S2 * T0) % 4 == 0, "f2 windows must keep float4 alignment");
+    __shared__ float red[2][TMAX * 8][64];            // [ti half][acc index][lane]: partial sums of channel half 1
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    // unit = (n, y, tj, xchunk); 4 units (waves) per workgroup
-    long unit = (long)blockIdx.x * 4 + wave;
-    if (unit >= units) return;  // wave-uniform tail guard (no workgroup barrier in this kernel)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int th = wave & 1, ch = wave >> 1;          // displacement half, channel half
+    long unit = blockIdx.x;
     const int xc = (int)(unit % xchunks); unit /= xchunks;
     const int tj = (int)(unit % D) - DR;  unit /= D;
     const int y = (int)(unit % H);
     const int n = (int)(unit / H);
 
+    const int t0 = th ? T0 : 0, nt = th ? D - T0 : T0;   // this wave's ti range [t0, t0+nt)
     const int xo = lane & 15, cs = lane >> 4;
     const int x0 = xc * 128 + xo * 8;
     const int y2 = y + tj * S2;
-    const bool row_ok = (y2 >= 0) && (y2 < H);  // wave-uniform
+    const bool row_ok = (y2 >= 0) && (y2 < H);       // workgroup-uniform
     const bool lane_ok = x0 < W;
     const long hw = (long)H * W;
+    const int xb = x0 - HALO + S2 * t0;              // first f2 column of this wave's window (multiple of 4)
 
-    float acc[D][8];
+    float acc[TMAX][8];
 #pragma unroll
-    for (int t = 0; t < D; ++t)
+    for (int t = 0; t < TMAX; ++t)
 #pragma unroll
         for (int m = 0; m < 8; ++m) acc[t][m] = 0.f;
 
     if (row_ok && lane_ok) {
         const float *p1 = f1 + ((long)n * C) * hw + (long)y * W + x0;
-        const float *p2 = f2 + ((long)n * C) * hw + (long)y2 * W + (x0 - HALO);
+        const float *p2 = f2 + ((long)n * C) * hw + (long)y2 * W + xb;
         bool inb[NB4];
 #pragma unroll
         for (int j = 0; j < NB4; ++j) {
-            int xs = x0 - HALO + 4 * j;
+            int xs = xb + 4 * j;
             inb[j] = (xs >= 0) && (xs + 3 < W);
         }
-        for (int c = cs; c < C; c += 4) {
+        // channels of this wave: c = 2*(4*i + cs) + ch  -> halves interleave, quarters interleave
+        for (int c = 2 * cs + ch; c < C; c += 8) {
             const float4 *a4 = reinterpret_cast<const float4 *>(p1 + (long)c * hw);
             const float4 *b4 = reinterpret_cast<const float4 *>(p2 + (long)c * hw);
-            float a[8], b[NB];
-            float4 t0 = a4[0], t1 = a4[1];
-            a[0] = t0.x; a[1] = t0.y; a[2] = t0.z; a[3] = t0.w;
-            a[4] = t1.x; a[5] = t1.y; a[6] = t1.z; a[7] = t1.w;
+            float a[8], b[NB4 * 4];
+            float4 u0 = a4[0], u1 = a4[1];
+            a[0] = u0.x; a[1] = u0.y; a[2] = u0.z; a[3] = u0.w;
+            a[4] = u1.x; a[5] = u1.y; a[6] = u1.z; a[7] = u1.w;
 #pragma unroll
             for (int j = 0; j < NB4; ++j) {
                 float4 v = inb[j] ? b4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
                 b[4 * j] = v.x; b[4 * j + 1] = v.y; b[4 * j + 2] = v.z; b[4 * j + 3] = v.w;
             }
 #pragma unroll
-            for (int t = 0; t < D; ++t)
+            for (int t = 0; t < TMAX; ++t)
 #pragma unroll
-                for (int m = 0; m < 8; ++m) acc[t][m] = fmaf(a[m], b[m + S2 * t], acc[t][m]);
+                for (int m = 0; m < 8; ++m)
+                    if (t < nt) acc[t][m] = fmaf(a[m], b[m + S2 * t], acc[t][m]);
         }
     }
 
-    // combine the 4 channel quarters: lanes l, l^16, l^32, l^48 hold partial sums of one tile
+    // lane quarters -> every lane holds the wave's sum
 #pragma unroll
-    for (int t = 0; t < D; ++t)
+    for (int t = 0; t < TMAX; ++t)
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             float v = acc[t][m];
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
-            acc[t][m] = v * inv_nelems;
+            acc[t][m] = v;
         }
-
-    if (lane_ok) {
-        // out[n][(tj+DR)*D + t][y][x0..x0+7]; quarter cs stores rows t = cs, cs+4, ...
-        float *o = out + (((long)n * (D * D) + (long)(tj + DR) * D) * H + y) * (long)W + x0;
+    // channel halves meet in LDS: waves with ch == 1 publish, waves with ch == 0 add and store
+    if (ch == 1) {
 #pragma unroll
-        for (int t = 0; t < D; ++t) {
-            if ((t & 3) == cs) {
+        for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+            for (int m = 0; m < 8; ++m) red[th][t * 8 + m][lane] = acc[t][m];
+    }
+    __syncthreads();
+    if (ch == 0 && lane_ok) {
+        float *o = out + (((long)n * (D * D) + (long)(tj + DR) * D + t0) * H + y) * (long)W + x0;
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) {
+            if (t < nt && (t & 3) == cs) {   // lane quarter cs stores rows t = cs, cs+4, ...
+                float r[8];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) r[m] = (acc[t][m] + red[th][t * 8 + m][lane]) * inv_nelems;
                 float4 *q = reinterpret_cast<float4 *>(o + (long)t * hw);
-                q[0] = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
-                q[1] = make_float4(acc[t][4], acc[t][5], acc[t][6], acc[t][7]);
+                q[0] = make_float4(r[0], r[1], r[2], r[3]);
+                q[1] = make_float4(r[4], r[5], r[6], r[7]);
             }
         }
     }
@@ -245,9 +267,8 @@ extern "C" int ir2rgb_correlation_fwd(const float *in1, const float *in2, float 
                       drad == 10 && max_displacement == 20 && (W % 8 == 0) && aligned && C > 0;
     if (fast) {
         int xchunks = cdiv(W, 128);
-        long units = (long)N * H * 21 * xchunks;  // (n, y, tj, xchunk)
-        long blocks = (units + 3) / 4;
-        corr_fwd_tile<10, 2><<<(unsigned)blocks, 256, 0, s>>>(in1, in2, out, C, H, W, xchunks, units, inv);
+        long units = (long)N * H * 21 * xchunks;  // (n, y, tj, xchunk): one workgroup each
+        corr_fwd_tile<10, 2, 12><<<(unsigned)units, 256, 0, s>>>(in1, in2, out, C, H, W, xchunks, inv);
         return ir2rgb_launch_status();
     }
     corr_fwd_generic<<<stream_grid(total, 256), 256, 0, s>>>(in1, in2, out, C, H, W, pad_size,
