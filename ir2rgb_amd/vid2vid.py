@@ -297,11 +297,37 @@ class Vid2VidTrainer:
         keep = tD ** (t_scales - 1) * (tD - 1)
         return B_all[:, -keep:] if B_all.size(1) > keep else B_all, skipped
 
-    def skipped_frames(self, real_B, fake_B, flow_ref, conf_ref):
-        """get_all_skipped_frames, dense variant (discriminator.py:219-234, :273-283)."""
+    def reference_flows(self, real_B, real_B_prev):
+        """All FlowNet2 evaluations of one window in ONE batched call: the reference flow of the current
+        frame (train_vid2vid.py:65) and the flows of the temporally skipped real triplets
+        (discriminator.py:281-283).  Both depend on real frames only, so batching them changes nothing
+        numerically (FlowNet2 is per-sample, frozen, eval mode)."""
         ts = self.t_scales
-        rb_all, fb_all, fl_all, cf_all = self.frames_all
-        rb_all, rb_s = self._skipped(rb_all, real_B, ts)
+        rb_all, rb_s = self._skipped(self.frames_all[0], real_B, ts)
+        self.frames_all[0] = rb_all
+        firsts, seconds, owners = [real_B.reshape((-1,) + tuple(real_B.shape[2:]))], [real_B_prev.reshape((-1,) + tuple(real_B.shape[2:]))], []
+        for s in range(1, ts):
+            if rb_s[s] is not None and rb_s[s].size(1) == self.tD:
+                a, b = rb_s[s][:, 1:], rb_s[s][:, :-1]
+                firsts.append(a.reshape((-1,) + tuple(a.shape[2:])))
+                seconds.append(b.reshape((-1,) + tuple(b.shape[2:])))
+                owners.append((s, a.shape[0], a.shape[1]))
+        flow, conf = self.flow_net(torch.cat(firsts), torch.cat(seconds))
+        n0 = firsts[0].shape[0]
+        b, t = real_B.shape[:2]
+        h, w = real_B.shape[-2:]
+        flow_ref, conf_ref = flow[:n0].view(b, t, 2, h, w), conf[:n0].view(b, t, 1, h, w)
+        extra, off = {}, n0
+        for s, bb, tt in owners:
+            extra[s] = (flow[off:off + bb * tt].view(bb, tt, 2, h, w), conf[off:off + bb * tt].view(bb, tt, 1, h, w))
+            off += bb * tt
+        return flow_ref, conf_ref, rb_s, extra
+
+    def skipped_frames(self, rb_s, extra_flows, fake_B, flow_ref, conf_ref):
+        """get_all_skipped_frames, dense variant (discriminator.py:219-234, :273-283); the real-frame
+        bookkeeping and the FlowNet2 calls were done by reference_flows."""
+        ts = self.t_scales
+        _, fb_all, fl_all, cf_all = self.frames_all
         fb_all, fb_s = self._skipped(fb_all, fake_B, ts)
         fl_all, fl0 = self._skipped(fl_all, flow_ref, 1)
         cf_all, cf0 = self._skipped(cf_all, conf_ref, 1)
@@ -309,9 +335,9 @@ class Vid2VidTrainer:
         if fl0[0] is not None:
             fl_s[0], cf_s[0] = fl0[0][:, 1:], cf0[0][:, 1:]
         for s in range(1, ts):
-            if rb_s[s] is not None and rb_s[s].size(1) == self.tD:
-                fl_s[s], cf_s[s] = self.flow_net(rb_s[s][:, 1:], rb_s[s][:, :-1])
-        self.frames_all = [rb_all, fb_all, fl_all, cf_all]
+            if s in extra_flows:
+                fl_s[s], cf_s[s] = extra_flows[s]
+        self.frames_all[1:] = [fb_all, fl_all, cf_all]
         return rb_s, fb_s, fl_s, cf_s
 
     # ------------------------------------------------------------------ the loop body (a14)
@@ -320,7 +346,7 @@ class Vid2VidTrainer:
         fake_prev_last = self.fake_B_prev
         fake_B, fake_B_raw, flow, weight, real_A, real_Bp = self.generate(input_A, input_B)
         real_B_prev, real_B = real_Bp[:, :-1], real_Bp[:, 1:]
-        flow_ref, conf_ref = self.flow_net(real_B, real_B_prev)
+        flow_ref, conf_ref, rb_s, extra_flows = self.reference_flows(real_B, real_B_prev)
         # compute_fake_B_prev (generator.py:283-287)
         fbp = real_B_prev[:, 0:1] if fake_prev_last is None else fake_prev_last[0][:, -1:]
         if fake_B.size(1) > 1:
@@ -328,7 +354,7 @@ class Vid2VidTrainer:
         flat = lambda t: t.reshape((-1,) + tuple(t.shape[2:]))  # noqa: E731
         L = self.image_losses(flat(real_B), flat(fake_B), flat(fake_B_raw), flat(real_A), flat(real_B_prev), flat(fbp),
                               flat(flow), flat(weight), flat(flow_ref), flat(conf_ref))
-        rb_s, fb_s, fl_s, cf_s = self.skipped_frames(real_B, fake_B, flow_ref, conf_ref)
+        rb_s, fb_s, fl_s, cf_s = self.skipped_frames(rb_s, extra_flows, fake_B, flow_ref, conf_ref)
         LT = [self.temporal_losses(s, rb_s[s], fb_s[s], fl_s[s], cf_s[s]) for s in range(self.t_scales) if rb_s[s] is not None]
         # get_losses (discriminator.py:236-248)
         loss_D = (L["D_fake"] + L["D_real"]) * 0.5
