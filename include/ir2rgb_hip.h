@@ -201,8 +201,8 @@ int ir2rgb_warp_blend_fwd(const float *raw, const float *prev, const float *flow
  * ------------------------------------------------------------------------------------------ */
 
 /* Rows R of the scratch needed by ir2rgb_bn_bwd: `partial` must hold (R*2 + 3)*C floats
- * ([R][2][C] block partial sums followed by three coefficient vectors).  < 0: error; C must be a
- * power of two in [64, 2048]. */
+ * ([R][2][C] pixel-range partial sums followed by three coefficient vectors).  < 0: error; C must
+ * be a power of two in [64, 2048]. */
 int ir2rgb_bn_bwd_blocks(long npix, int C);
 
 /* Backward of activation + training-mode BatchNorm2d on NHWC half tensors:

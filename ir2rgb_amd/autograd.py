@@ -13,6 +13,7 @@ are HIP, as are the backward of the separable head convolutions and of the warp-
 convolution is left on the generator / discriminator path, forward or backward.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn.functional as F
@@ -154,6 +155,52 @@ def conv_wgrad(x, gy, weight_shape, spec):
 
 
 # ---------------------------------------------------------------------------------------------
+# weight gradients on a second HIP stream.  The data-gradient chain (dgrad conv -> fold -> BN
+# backward of the layer below) is the critical path of loss.backward(); the weight gradient of a
+# layer only feeds the optimizer, so it runs beside that chain and fills the CUs the chain's small
+# launches leave idle.  Only a parameter's FIRST contribution of a backward pass goes to the side
+# stream (autograd adopts it without touching it); a later contribution is accumulated in place by
+# autograd on the main stream, so it is computed there after the side stream has been joined.
+# The side stream is joined again when the backward pass ends (engine callback).
+# ---------------------------------------------------------------------------------------------
+WGRAD_SIDE_STREAM = os.environ.get("IR2RGB_WGRAD_STREAM", "1") != "0"
+_SIDE = {}
+
+
+def _join_side(dev_index):
+    st = _SIDE[dev_index]
+    st["pending"] = False
+    C.SIDE_BUSY = False
+    torch.cuda.current_stream(dev_index).wait_stream(st["stream"])
+
+
+def wgrad_overlapped(param, fn, *inputs):
+    """Run ``fn()`` (a weight-gradient computation reading ``inputs``) on the side stream when that is
+    safe for ``param`` (see above), else on the current stream."""
+    dev = inputs[0].device
+    if not WGRAD_SIDE_STREAM or dev.type != "cuda":
+        return fn()
+    st = _SIDE.get(dev.index)
+    if st is None:
+        st = _SIDE[dev.index] = {"stream": torch.cuda.Stream(dev), "pending": False}
+    main, side = torch.cuda.current_stream(dev), st["stream"]
+    if param.grad is not None:
+        main.wait_stream(side)
+        return fn()
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        out = fn()
+    for t in inputs:
+        t.record_stream(side)
+    out.record_stream(main)
+    if not st["pending"]:
+        st["pending"] = True
+        C.SIDE_BUSY = True
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: _join_side(dev.index))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
 # the fused stage
 # ---------------------------------------------------------------------------------------------
 class ConvStageFn(Function):
@@ -237,14 +284,16 @@ class ConvStageFn(Function):
         dw = None
         if ctx.needs_input_grad[1]:
             if spec["first"]:
-                kh, kw = conv.kernel_size
-                sub = dict(spec, k=(kh, 1), stride=(spec["stride"][0], 1), pad=(spec["pad"][0], 0))
-                gwe = conv_wgrad(xin, gy, (conv.out_channels, 64, kh, 1), sub)      # [co][64][kh][1]
-                cin = conv.in_channels
-                gwe = gwe[:, :cin * kw, :, 0].reshape(conv.out_channels, cin, kw, kh)  # [co][ci][kx][ky]
-                dw = gwe.permute(0, 1, 3, 2).contiguous()
+                def first_wgrad():
+                    kh, kw = conv.kernel_size
+                    sub = dict(spec, k=(kh, 1), stride=(spec["stride"][0], 1), pad=(spec["pad"][0], 0))
+                    gwe = conv_wgrad(xin, gy, (conv.out_channels, 64, kh, 1), sub)      # [co][64][kh][1]
+                    cin = conv.in_channels
+                    gwe = gwe[:, :cin * kw, :, 0].reshape(conv.out_channels, cin, kw, kh)  # [co][ci][kx][ky]
+                    return gwe.permute(0, 1, 3, 2).contiguous()
+                dw = wgrad_overlapped(conv.weight, first_wgrad, xin, gy)
             else:
-                dw = conv_wgrad(xin, gy, tuple(conv.weight.shape), spec)
+                dw = wgrad_overlapped(conv.weight, lambda: conv_wgrad(xin, gy, tuple(conv.weight.shape), spec), xin, gy)
         r1 = gz if ctx.has_res[0] else None
         r2 = gz if ctx.has_res[1] else None
         return dx, dw, (dbias if ctx.needs_input_grad[2] else None), dgamma, dbeta, r1, r2, None, None, None

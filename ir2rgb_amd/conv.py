@@ -74,9 +74,38 @@ def stats_rows(desc):
     return r
 
 
-# Optional per-launch timing (bench.py's roofline leg): when PROFILE is a dict, every convolution is
-# bracketed by HIP events on the stream it is launched on and tallied by shape.
+# Optional per-launch timing (bench.py's roofline leg): when PROFILE is a dict, convolutions are
+# bracketed by HIP events on the stream they are launched on and tallied by shape -- every shape, or
+# only PROFILE["only"] when that key is set (an event pair costs a queue marker, so the timed region
+# of bench.py brackets just the dominant shape).  Launches issued while weight-gradient work is in
+# flight on the side stream (SIDE_BUSY, set by ir2rgb_amd.autograd) share the GPU and are skipped: the
+# events would time the overlap, not the kernel.
 PROFILE = None
+SIDE_BUSY = False
+
+
+def _prof_key(desc):
+    return (desc.Cin, desc.Hin, desc.Win, desc.Cout, desc.kh, desc.kw, desc.stride_h, desc.pad_mode, desc.transposed)
+
+
+def _prof_begin(desc):
+    prof = PROFILE
+    if prof is None or SIDE_BUSY:
+        return None
+    key = _prof_key(desc)
+    only = prof.get("only")
+    if only is not None and only != key:
+        return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return prof, key, e0
+
+
+def _prof_end(tok, desc):
+    prof, key, e0 = tok
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    prof.setdefault("shapes", {}).setdefault(key, {"flops": _flops(desc), "events": []})["events"].append((e0, e1))
 
 
 def _flops(desc):
@@ -100,18 +129,13 @@ def conv2d_fwd(desc, x, wpacked, bias=None, want_stats=False, out=None):
     stats = None
     if want_stats:
         stats = torch.empty((stats_rows(desc), 2, desc.Cout), dtype=torch.float32, device=x.device)
-    prof = PROFILE
-    if prof is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+    tok = _prof_begin(desc)
     with _lib.on_device(x):
         rc = _lib.lib().ir2rgb_conv2d_fwd(ctypes.byref(desc), _p(x), _p(wpacked), _p(bias), _p(y), _p(stats),
                                           _lib.current_stream(x))
     _lib.check(rc, "conv2d_fwd")
-    if prof is not None:
-        e1.record()
-        key = (desc.Cin, desc.Hin, desc.Win, desc.Cout, desc.kh, desc.kw, desc.stride_h, desc.pad_mode, desc.transposed)
-        prof.setdefault(key, {"flops": _flops(desc), "events": []})["events"].append((e0, e1))
+    if tok is not None:
+        _prof_end(tok, desc)
     return y, stats
 
 
@@ -140,15 +164,10 @@ def conv2d_fwd_view(desc, xbuf, wpacked, bias, ybuf, stats=None):
     checks beyond device / alignment: the caller (flownet2_hip) owns the buffer geometry."""
     if not (xbuf.is_cuda and ybuf.is_cuda):
         raise ValueError("conv2d_fwd_view: GPU tensors only (no CPU fallback)")
-    prof = PROFILE
-    if prof is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+    tok = _prof_begin(desc)
     with _lib.on_device(xbuf):
         rc = _lib.lib().ir2rgb_conv2d_fwd(ctypes.byref(desc), _p(xbuf), _p(wpacked), _p(bias), _p(ybuf), _p(stats),
                                           _lib.current_stream(xbuf))
     _lib.check(rc, "conv2d_fwd")
-    if prof is not None:
-        e1.record()
-        key = (desc.Cin, desc.Hin, desc.Win, desc.Cout, desc.kh, desc.kw, desc.stride_h, desc.pad_mode, desc.transposed)
-        prof.setdefault(key, {"flops": _flops(desc), "events": []})["events"].append((e0, e1))
+    if tok is not None:
+        _prof_end(tok, desc)

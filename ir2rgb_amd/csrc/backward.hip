@@ -41,81 +41,117 @@ __device__ __forceinline__ float act_grad(float g, float pre, int act) {
     return g;
 }
 
-// partial[blk][0][c] = sum g', partial[blk][1][c] = sum g' * yhat over this block's pixels.
-// Block = 256 threads; thread t owns channel octet t % (C/8) and pixel rows t / (C/8) + k*(256/(C/8)).
-__global__ void __launch_bounds__(256)
+// One block (1024 threads) = one 64-channel group x one pixel range.  partial[r][0][c] = sum g',
+// partial[r][1][c] = sum g' * yhat over range r.  Thread t owns channel octet t & 7 of the group
+// and pixel rows (t >> 3) + 128k of the range, four rows in flight: a dependent HBM round trip
+// costs ~2 us here, so these small reductions are shaped to need as few of them as possible.
+// (A last-block-finalises variant was measured: the device-scope fences it needs write back the
+// XCD L2s and made this kernel 4x slower than reduce + a separate finalize launch.)
+__global__ void __launch_bounds__(1024)
 bn_bwd_reduce_kernel(const uint4 *__restrict__ gz, const uint4 *__restrict__ y, const float *__restrict__ scale,
                      const float *__restrict__ shift, const float *__restrict__ mean, const float *__restrict__ invstd,
                      float *__restrict__ partial, long npix, int C, int act, int dt, long pix_per_block) {
-    __shared__ float red[2][256][9];  // [which][thread][8 (+1 pad)]
-    const int octs = C >> 3, rows = 256 / octs;
-    const int oc = threadIdx.x % octs, r0 = threadIdx.x / octs;
-    const long p_begin = (long)blockIdx.x * pix_per_block;
+    __shared__ float red[2][16][64];
+    const int octs = C >> 3, ngroups = C >> 6;
+    const int cg = blockIdx.x % ngroups, r = blockIdx.x / ngroups;
+    const int oc = threadIdx.x & 7, row = threadIdx.x >> 3, wave = threadIdx.x >> 6;
+    const long p_begin = (long)r * pix_per_block;
     const long p_end = min(npix, p_begin + pix_per_block);
+    const int c0 = cg * 64 + oc * 8;
     float s1[8], s2[8], sc[8], sh[8], mu[8], is[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         s1[j] = s2[j] = 0.f;
-        const int c = oc * 8 + j;
-        sc[j] = scale ? scale[c] : 1.f;
-        sh[j] = shift ? shift[c] : 0.f;
-        mu[j] = mean ? mean[c] : 0.f;
-        is[j] = invstd ? invstd[c] : 1.f;
+        sc[j] = scale ? scale[c0 + j] : 1.f;
+        sh[j] = shift ? shift[c0 + j] : 0.f;
+        mu[j] = mean ? mean[c0 + j] : 0.f;
+        is[j] = invstd ? invstd[c0 + j] : 1.f;
     }
-    for (long p = p_begin + r0; p < p_end; p += rows) {
-        float g[8], v[8];
-        unpack8(gz[p * octs + oc], g, dt);
-        unpack8(y[p * octs + oc], v, dt);
+    const long lane_off = (long)cg * 8 + oc;
+    for (long p = p_begin + row; p < p_end; p += 512) {
+        uint4 gq[4], yq[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float gp = act_grad(g[j], v[j] * sc[j] + sh[j], act);
-            s1[j] += gp;
-            s2[j] += gp * (v[j] - mu[j]) * is[j];
+        for (int u = 0; u < 4; ++u) {
+            const long q = p + 128 * u;
+            const bool ok = q < p_end;
+            gq[u] = ok ? gz[q * octs + lane_off] : make_uint4(0, 0, 0, 0);
+            yq[u] = ok ? y[q * octs + lane_off] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float g[8], v[8];
+            unpack8(gq[u], g, dt);
+            unpack8(yq[u], v, dt);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float gp = act_grad(g[j], v[j] * sc[j] + sh[j], act);   // g == 0 for the padding rows
+                s1[j] += gp;
+                s2[j] += gp * (v[j] - mu[j]) * is[j];
+            }
         }
     }
+    // the 8 pixel rows of a wave (lane bits 3..5), then the 16 waves through LDS in wave order
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { red[0][threadIdx.x][j] = s1[j]; red[1][threadIdx.x][j] = s2[j]; }
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int m = 8; m < 64; m <<= 1) {
+            s1[j] += __shfl_xor(s1[j], m);
+            s2[j] += __shfl_xor(s2[j], m);
+        }
+    }
+    if ((threadIdx.x & 63) < 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { red[0][wave][oc * 8 + j] = s1[j]; red[1][wave][oc * 8 + j] = s2[j]; }
+    }
     __syncthreads();
-    // thread t < 2*C: which = t / C, channel c = t % C  (2*C may exceed 256: loop)
-    for (int t = threadIdx.x; t < 2 * C; t += 256) {
-        const int which = t / C, c = t - which * C, o = c >> 3, j = c & 7;
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, cl = threadIdx.x & 63;
         float s = 0.f;
-        for (int r = 0; r < rows; ++r) s += red[which][r * octs + o][j];
-        partial[((long)blockIdx.x * 2 + which) * C + c] = s;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[which][k][cl];
+        partial[((long)r * 2 + which) * C + cg * 64 + cl] = s;
     }
 }
 
-// dbeta[c] = sum_blocks partial[.][0][c], dgamma[c] = sum_blocks partial[.][1][c]
-// (32 channels x 32 row groups per block, as bn_finalize_kernel).  Also emits the three coefficient
-// vectors of the apply pass:  gy = cA*g' + cB*y + cC  with
+// One block (1024 threads) per 64-channel group: dbeta[c] = sum_r partial[r][0][c],
+// dgamma[c] = sum_r partial[r][1][c] (R <= 128 rows: thread = (value, slice of 16 rows), every load
+// of a thread in flight at once; slices and rows are added in a fixed order, in double), and the
+// three coefficient vectors of the apply pass:  gy = cA*g' + cB*y + cC
 //   cA = scale, cB = -scale*invstd*dgamma/n, cC = scale*(invstd*mean*dgamma/n - dbeta/n).
 __global__ void __launch_bounds__(1024)
-bn_bwd_finalize_kernel(const float *__restrict__ partial, int nblk, int C, const float *__restrict__ scale,
+bn_bwd_finalize_kernel(const float *__restrict__ partial, int R, int C, const float *__restrict__ scale,
                        const float *__restrict__ mean, const float *__restrict__ invstd, float inv_n,
                        float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ coef) {
-    __shared__ double red[2][32][33];
-    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
-    double a = 0.0, b = 0.0;
-    if (c < C)
-        for (int r = rg; r < nblk; r += 32) {
-            a += (double)partial[((long)r * 2 + 0) * C + c];
-            b += (double)partial[((long)r * 2 + 1) * C + c];
+    __shared__ double fin[8][2][64];
+    const int cg = blockIdx.x;
+    {
+        const int slice = threadIdx.x >> 7, which = (threadIdx.x >> 6) & 1, cl = threadIdx.x & 63;
+        float t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int k = slice + 8 * u;
+            t[u] = k < R ? partial[((long)k * 2 + which) * C + cg * 64 + cl] : 0.f;
         }
-    red[0][rg][cl] = a;
-    red[1][rg][cl] = b;
+        double a = 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) a += (double)t[u];
+        fin[slice][which][cl] = a;
+    }
     __syncthreads();
-    if (rg != 0 || c >= C) return;
-    a = b = 0.0;
-    for (int r = 0; r < 32; ++r) { a += red[0][r][cl]; b += red[1][r][cl]; }
-    dbeta[c] = (float)a;
-    dgamma[c] = (float)b;
-    if (scale) {
-        const float sc = scale[c], is = invstd[c], mu = mean[c];
-        const float dg = (float)b * inv_n, db = (float)a * inv_n;
-        coef[c] = sc;
-        coef[C + c] = -sc * is * dg;
-        coef[2 * C + c] = sc * (is * mu * dg - db);
+    if (threadIdx.x < 64) {
+        const int cl = threadIdx.x, c = cg * 64 + cl;
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { a += fin[k][0][cl]; b += fin[k][1][cl]; }
+        dbeta[c] = (float)a;
+        dgamma[c] = (float)b;
+        if (scale) {
+            const float scv = scale[c], isv = invstd[c], muv = mean[c];
+            const float dg = (float)b * inv_n, db = (float)a * inv_n;
+            coef[c] = scv;
+            coef[C + c] = -scv * isv * dg;
+            coef[2 * C + c] = scv * (isv * muv * dg - db);
+        }
     }
 }
 
@@ -220,34 +256,38 @@ xexpand_bwd_kernel(const uint16_t *__restrict__ dxe, float *__restrict__ din, in
     }
 }
 
-static long bn_bwd_pixels_per_block(long npix, int C) {
-    const long rows = 256 / (C / 8);                 // pixel rows one block covers per loop iteration
-    long per = (npix + 1023) / 1024;                 // aim for ~1024 blocks
-    per = ((per + rows - 1) / rows) * rows;
-    return per < rows ? rows : per;
+// R pixel ranges per 64-channel group: about 512 blocks of 1024 threads in all, at least 128 pixels
+// per range and at most 128 ranges (bn_bwd_finalize_kernel's 8 slices x 16 rows).
+static int bn_bwd_ranges(long npix, int C) {
+    long want = 512 / (C / 64);
+    want = want < 8 ? 8 : (want > 128 ? 128 : want);
+    const long cap = (npix + 127) / 128;
+    return (int)(want < cap ? want : cap);
 }
 
 extern "C" int ir2rgb_bn_bwd_blocks(long npix, int C) {
     if (npix < 1 || C < 64 || (C & (C - 1)) || C > 2048) return IR2RGB_EINVAL;
-    const long per = bn_bwd_pixels_per_block(npix, C);
+    const int R = bn_bwd_ranges(npix, C);
+    const long per = (npix + R - 1) / R;
     return (int)((npix + per - 1) / per);
 }
 
 extern "C" int ir2rgb_bn_bwd(const void *gz, const void *y, const float *scale, const float *shift, const float *mean,
                              const float *invstd, void *gy, float *dgamma, float *dbeta, float *partial, long npix,
                              int C, int act, int dtype, void *stream) {
-    int nblk = ir2rgb_bn_bwd_blocks(npix, C);
-    if (nblk < 0) return nblk;
+    const int R = ir2rgb_bn_bwd_blocks(npix, C);
+    if (R < 0) return R;
     if (dtype != IR2RGB_BF16 && dtype != IR2RGB_F16) return IR2RGB_ENOSUP;
     if (!gz || !y || !gy || !dgamma || !dbeta || !partial || act < 0 || act > 2) return IR2RGB_EINVAL;
-    const long per = bn_bwd_pixels_per_block(npix, C);
+    const int R0 = bn_bwd_ranges(npix, C);
+    const long per = (npix + R0 - 1) / R0;
     hipStream_t s = as_stream(stream);
-    // partial holds nblk*2*C floats followed by 3*C coefficient floats (see ir2rgb_hip.h)
-    float *coef = partial + (long)nblk * 2 * C;
-    bn_bwd_reduce_kernel<<<nblk, 256, 0, s>>>((const uint4 *)gz, (const uint4 *)y, scale, shift, mean, invstd, partial,
-                                              npix, C, act, dtype, per);
-    bn_bwd_finalize_kernel<<<cdiv(C, 32), 1024, 0, s>>>(partial, nblk, C, scale, mean, invstd, 1.0f / (float)npix, dgamma,
-                                                        dbeta, coef);
+    // partial holds R*2*C floats followed by 3*C coefficient floats (see ir2rgb_hip.h)
+    float *coef = partial + (long)R * 2 * C;
+    bn_bwd_reduce_kernel<<<R * (C / 64), 1024, 0, s>>>((const uint4 *)gz, (const uint4 *)y, scale, shift, mean, invstd,
+                                                      partial, npix, C, act, dtype, per);
+    bn_bwd_finalize_kernel<<<C / 64, 1024, 0, s>>>(partial, R, C, scale, mean, invstd, 1.0f / (float)npix, dgamma, dbeta,
+                                                  coef);
     long total8 = npix * (C / 8);
     bn_bwd_apply_kernel<<<stream_grid(total8, 256), 256, 0, s>>>((const uint4 *)gz, (const uint4 *)y, scale, shift, coef,
                                                                  (uint4 *)gy, total8, C / 8, act, dtype);

@@ -129,27 +129,41 @@ class FlowNet(torch.nn.Module):
 
 
 class FlatGrads:
-    """Parameters' .grad as views of one flat fp32 buffer: a single RCCL all-reduce per optimizer
-    (chunked so each collective is ~128 MB) with no pack / unpack copies."""
+    """One flat fp32 gradient buffer per optimizer.  ``zero`` drops the .grad references, so the first
+    contribution of a backward pass is adopted by autograd without an add kernel per parameter;
+    ``all_reduce_async`` gathers the adopted tensors into the flat buffer with one multi-tensor copy
+    (world > 1 only), re-points .grad at the views and issues a chunked RCCL all-reduce (~128 MB per
+    collective).  A parameter that received no gradient gets a zero one, as the reference's
+    zero_grad() + Adam step would see (train_vid2vid.py:93-105)."""
 
     def __init__(self, params, chunk_elems=32 * 1024 * 1024):
         self.params = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        off = 0
+        self.views, off = [], 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
         self.chunk = chunk_elems
         self.handles = []
 
     def zero(self):
-        self.flat.zero_()
+        for p in self.params:
+            p.grad = None
 
     def all_reduce_async(self, world):
+        src, dst = [], []
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                p.grad = v.zero_()
+            elif world > 1:
+                src.append(p.grad)
+                dst.append(v)
+                p.grad = v
         if world <= 1:
             return
+        torch._foreach_copy_(dst, src)
         self.flat.mul_(1.0 / world)
         for i in range(0, self.flat.numel(), self.chunk):
             self.handles.append(dist.all_reduce(self.flat[i:i + self.chunk], op=dist.ReduceOp.SUM, async_op=True))

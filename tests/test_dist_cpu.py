@@ -39,8 +39,9 @@ def _worker(rank, world, port, outdir):
     for _ in range(3):
         fg.zero()
         torch.nn.functional.mse_loss(m(x), y).backward()
-        assert all(p.grad.data_ptr() >= fg.flat.data_ptr() for p in fg.params)  # still views of the flat buffer
         fg.all_reduce_async(world)
+        lo, hi = fg.flat.data_ptr(), fg.flat.data_ptr() + fg.flat.numel() * 4
+        assert all(lo <= p.grad.data_ptr() < hi for p in fg.params)  # gathered: views of the flat buffer
         fg.wait()
         opt.step()
     torch.save((rank, fg.flat.clone(), torch.cat([p.detach().reshape(-1) for p in m.parameters()])),
