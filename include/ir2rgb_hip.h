@@ -249,6 +249,42 @@ int ir2rgb_conv2d_wgrad(const ir2rgb_conv_desc *d, const void *x, const void *gy
 int ir2rgb_flow_upsample_slice(const float *in, const float *weight, const float *bias, void *out, int N, int h,
                                int w, int ld, int c_off, int dtype, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Scalar losses of the loop body, a group of terms per launch.  Replaces the chains of torch
+ * elementwise + reduction kernels behind criterionFeat (nn.L1Loss on discriminator features,
+ * reference discriminator.py:199-210), criterionGAN (least-squares GANLoss, models/networks.py
+ * GANLoss / loss.py) and the confidence-masked L1 terms (criterionFlow, loss.py MaskedL1Loss).
+ *   kind 0: weight * mean |a - b|          a, b half tensors of identical dense layout, n % 8 == 0
+ *   kind 1: weight * mean (a - target)^2   a fp32
+ *   kind 2: weight * mean |a*m - b*m|      a, b fp32 NCHW [N,C,H,W] (b NULL = zeros), mask fp32
+ *                                          [N,1,H,W]; hw = H*W, chw = C*H*W
+ * Every term adds into out[slot] (slot 0..3).  The sums are deterministic (per-block partials added
+ * in block order).  ga, when not NULL, receives d out[slot] / d a scaled by gout[slot] (same dtype
+ * and layout as a).
+ * ------------------------------------------------------------------------------------------ */
+#define IR2RGB_LOSS_MAX_ITEMS 16
+typedef struct ir2rgb_loss_item {
+    const void *a;
+    const void *b;
+    void *ga;
+    const void *mask;
+    long n;
+    long hw;
+    long chw;
+    float weight;
+    float target;
+    int kind;
+    int slot;
+} ir2rgb_loss_item;
+
+/* Floats of `partial` scratch that ir2rgb_loss_multi_fwd needs. */
+int ir2rgb_loss_partial_elems(void);
+/* out[0 .. max slot] = the summed terms (slots no term names are not written). */
+int ir2rgb_loss_multi_fwd(const ir2rgb_loss_item *items, int count, int dtype, float *partial, float *out,
+                          void *stream);
+/* Writes items[i].ga for every item that has one; gout = gradient w.r.t. out (device, fp32). */
+int ir2rgb_loss_multi_bwd(const ir2rgb_loss_item *items, int count, int dtype, const float *gout, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

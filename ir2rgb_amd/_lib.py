@@ -24,6 +24,17 @@ class ConvDesc(ctypes.Structure):
 
 _pdesc = ctypes.POINTER(ConvDesc)
 
+LOSS_MAX_ITEMS = 16
+
+
+class LossItem(ctypes.Structure):
+    """ir2rgb_loss_item of include/ir2rgb_hip.h."""
+    _fields_ = [("a", c_void_p), ("b", c_void_p), ("ga", c_void_p), ("mask", c_void_p), ("n", c_long), ("hw", c_long),
+                ("chw", c_long), ("weight", c_float), ("target", c_float), ("kind", c_int), ("slot", c_int)]
+
+
+_pitem = ctypes.POINTER(LossItem)
+
 # name -> (restype, argtypes)
 PROTOTYPES = {
     "ir2rgb_version": (ctypes.c_char_p, []),
@@ -58,6 +69,9 @@ PROTOTYPES = {
     "ir2rgb_xexpand_bwd": (c_int, [P, P] + [c_int] * 10 + [P]),
     "ir2rgb_conv2d_wgrad_workspace_elems": (c_long, [_pdesc]),
     "ir2rgb_conv2d_wgrad": (c_int, [_pdesc, P, P, P, P, P]),
+    "ir2rgb_loss_partial_elems": (c_int, []),
+    "ir2rgb_loss_multi_fwd": (c_int, [_pitem, c_int, c_int, P, P, P]),
+    "ir2rgb_loss_multi_bwd": (c_int, [_pitem, c_int, c_int, P, P]),
 }
 
 _lib = None

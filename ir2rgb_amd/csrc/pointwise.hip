@@ -165,38 +165,56 @@ nhwc_to_nchw_kernel(const uint16_t *__restrict__ in, float *__restrict__ out, in
 //   in NCHW fp32 (Cin*KW <= 64), out NHWC half with 64 channels.  One lane per 8 output
 //   channels (16-byte stores); the NCHW reads of a wave walk x, so they coalesce per (ci,kx).
 // ----------------------------------------------------------------------------------------
+// One block = one image row (n, y) x XE_TW output columns: the fp32 row segments of all Cin planes
+// are staged in LDS with coalesced reads (padding resolved there), then every lane assembles its 8
+// output channels -- whose (ci, kx) pairs are fixed for the lane -- and stores 16 B.
+#define XE_TW 128
 template <int DT>
 __global__ void __launch_bounds__(256)
 xexpand_kernel(const float *__restrict__ in, uint4 *__restrict__ out, int Cin, int H, int W, int Wout, int KW,
-               int sx, int px, int pad_mode, int lanes, long total) {
-    // total = N*H*Wout*lanes (lanes = Cx/8 lanes per output pixel)
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int j0 = (int)(i % lanes) * 8;
-        long pix = i / lanes;
-        const int ox = (int)(pix % Wout); pix /= Wout;
-        const int y = (int)(pix % H);
-        const int n = (int)(pix / H);
-        uint32_t o[4];
+               int sx, int px, int pad_mode, int lanes, int xtiles) {
+    extern __shared__ float seg[];                       // [Cin][span]
+    const int xt = blockIdx.x % xtiles;
+    const long row = blockIdx.x / xtiles;                // n*H + y
+    const int n = (int)(row / H), y = (int)(row - (long)n * H);
+    const int ox0 = xt * XE_TW;
+    const int tw = min(XE_TW, Wout - ox0);
+    const int span = (tw - 1) * sx + KW;
+    const int ix0 = ox0 * sx - px;
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float *src = in + (((long)n * Cin + ci) * H + y) * W;
+        for (int t = threadIdx.x; t < span; t += 256) {
+            int ix = ix0 + t;
+            float v = 0.f;
+            if (pad_mode) {
+                ix = ix < 0 ? -ix : ix;
+                ix = ix >= W ? 2 * W - 2 - ix : ix;
+                v = src[ix];
+            } else if (ix >= 0 && ix < W) {
+                v = src[ix];
+            }
+            seg[ci * ((XE_TW - 1) * sx + KW) + t] = v;
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x % lanes, slot = threadIdx.x / lanes, slots = 256 / lanes;
+    int off[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = lane * 8 + j;
+        const int ci = c / KW, kx = c - ci * KW;
+        off[j] = c < Cin * KW ? ci * ((XE_TW - 1) * sx + KW) + kx : -1;
+    }
+    uint4 *dst = out + (row * Wout + ox0) * lanes + lane;
+    for (int o = slot; o < tw; o += slots) {
+        uint32_t w[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            uint16_t hv[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int j = j0 + 2 * q + h;
-                float v = 0.f;
-                if (j < Cin * KW) {
-                    const int ci = j / KW, kx = j - ci * KW;
-                    int ix = ox * sx + kx - px;
-                    bool ok = true;
-                    if (pad_mode) { ix = ix < 0 ? -ix : ix; ix = ix >= W ? 2 * W - 2 - ix : ix; }
-                    else ok = ix >= 0 && ix < W;
-                    if (ok) v = in[(((long)n * Cin + ci) * H + y) * W + ix];
-                }
-                hv[h] = f2h(v, DT);
-            }
-            o[q] = (uint32_t)hv[0] | ((uint32_t)hv[1] << 16);
+            const float v0 = off[2 * q] >= 0 ? seg[off[2 * q] + o * sx] : 0.f;
+            const float v1 = off[2 * q + 1] >= 0 ? seg[off[2 * q + 1] + o * sx] : 0.f;
+            w[q] = (uint32_t)f2h(v0, DT) | ((uint32_t)f2h(v1, DT) << 16);
         }
-        out[i] = make_uint4(o[0], o[1], o[2], o[3]);
+        dst[(long)o * lanes] = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
 
@@ -265,13 +283,16 @@ extern "C" int ir2rgb_xexpand_cx(const float *in, void *out, int N, int Cin, int
     if ((Wout - 1) * stride_w + KW - pad_w > W + pad_w) return IR2RGB_EINVAL;  // would read past the padded row
     if (dtype != IR2RGB_BF16 && dtype != IR2RGB_F16) return IR2RGB_ENOSUP;
     const int lanes = Cx / 8;
-    long total = (long)N * H * Wout * lanes;
-    if (total == 0) return IR2RGB_OK;
-    int grid = stream_grid(total, 256);
+    if ((long)N * H * Wout == 0) return IR2RGB_OK;
+    const int xtiles = cdiv(Wout, XE_TW);
+    const long blocks = (long)N * H * xtiles;
+    if (blocks > 0x7fffffffL) return IR2RGB_EINVAL;
+    const size_t lds = (size_t)Cin * ((XE_TW - 1) * stride_w + KW) * sizeof(float);
+    if (lds > 64 * 1024) return IR2RGB_ENOSUP;
     if (dtype == IR2RGB_BF16)
-        xexpand_kernel<IR2RGB_BF16><<<grid, 256, 0, as_stream(stream)>>>(in, (uint4 *)out, Cin, H, W, Wout, KW, stride_w, pad_w, pad_mode, lanes, total);
+        xexpand_kernel<IR2RGB_BF16><<<(unsigned)blocks, 256, lds, as_stream(stream)>>>(in, (uint4 *)out, Cin, H, W, Wout, KW, stride_w, pad_w, pad_mode, lanes, xtiles);
     else
-        xexpand_kernel<IR2RGB_F16><<<grid, 256, 0, as_stream(stream)>>>(in, (uint4 *)out, Cin, H, W, Wout, KW, stride_w, pad_w, pad_mode, lanes, total);
+        xexpand_kernel<IR2RGB_F16><<<(unsigned)blocks, 256, lds, as_stream(stream)>>>(in, (uint4 *)out, Cin, H, W, Wout, KW, stride_w, pad_w, pad_mode, lanes, xtiles);
     return ir2rgb_launch_status();
 }
 

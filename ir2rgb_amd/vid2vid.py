@@ -21,6 +21,7 @@ import torch.distributed as dist
 import torch.nn.functional as F
 
 from . import networks
+from .losses import fused_losses
 from .ext import warp_diff_norm
 
 DEFAULTS = dict(  # options/base_options.py, options/train_options.py
@@ -29,6 +30,7 @@ DEFAULTS = dict(  # options/base_options.py, options/train_options.py (SURVEY se
     feat_num=3, first_layer_dis_filters=64, num_D=2, n_layers_D=3, no_ganFeat=False, n_frames_D=3, n_scales_temporal=2,
     lr=2e-4, beta1=0.5, lambda_feat=10.0, lambda_T=10.0, lambda_F=10.0, no_first_img=False, max_frames_per_gpu=1,
     n_frames_bp=1, compute_dtype=torch.bfloat16, flownet_dtype=torch.bfloat16,
+    fused_losses=True,   # grouped HIP loss kernels (ir2rgb_amd.losses); False = the same terms through torch ops
 )
 
 
@@ -252,10 +254,18 @@ class Vid2VidTrainer:
     # ------------------------------------------------------------------ discriminator losses (a13)
     def _gan_and_fm(self, pred_real, pred_fake):
         o = self.opt
+        fw, dw = 4.0 / (o["n_layers_D"] + 1), 1.0 / o["num_D"]
+        if o["fused_losses"]:
+            terms = [("mse", scale[-1], 1.0, 1.0, 0) for scale in pred_fake]
+            if not o["no_ganFeat"]:
+                for i in range(min(len(pred_fake), o["num_D"])):
+                    for j in range(len(pred_fake[i]) - 1):
+                        terms.append(("l1", pred_fake[i][j], pred_real[i][j], dw * fw * o["lambda_feat"], 1))
+            out = fused_losses(terms, 2, o["compute_dtype"])
+            return out[0], out[1]
         loss_gan = gan_loss(pred_fake, True)
         loss_fm = torch.zeros_like(loss_gan)
         if not o["no_ganFeat"]:
-            fw, dw = 4.0 / (o["n_layers_D"] + 1), 1.0 / o["num_D"]
             for i in range(min(len(pred_fake), o["num_D"])):
                 for j in range(len(pred_fake[i]) - 1):
                     loss_fm = loss_fm + dw * fw * (pred_fake[i][j] - pred_real[i][j].detach()).abs().mean(dtype=torch.float32) * o["lambda_feat"]
@@ -265,7 +275,12 @@ class Vid2VidTrainer:
         """Three forwards exactly as compute_loss_D (discriminator.py:154-166)."""
         pred_real = netD(real_in)
         pred_fake_d = netD(fake_in.detach())
-        loss_D_real, loss_D_fake = gan_loss(pred_real, True), gan_loss(pred_fake_d, False)
+        if self.opt["fused_losses"]:
+            out = fused_losses([("mse", scale[-1], 1.0, 1.0, 0) for scale in pred_real] +
+                               [("mse", scale[-1], 0.0, 1.0, 1) for scale in pred_fake_d], 2, self.opt["compute_dtype"])
+            loss_D_real, loss_D_fake = out[0], out[1]
+        else:
+            loss_D_real, loss_D_fake = gan_loss(pred_real, True), gan_loss(pred_fake_d, False)
         with frozen(netD):
             pred_fake = netD(fake_in)
         loss_G_GAN, loss_G_FM = self._gan_and_fm(pred_real, pred_fake)
@@ -274,12 +289,22 @@ class Vid2VidTrainer:
     def image_losses(self, real_B, fake_B, fake_B_raw, real_A, real_B_prev, fake_B_prev, flow, weight, flow_ref, conf_ref):
         o = self.opt
         L = {}
-        L["F_Flow"] = masked_l1(flow, flow_ref, conf_ref) * o["lambda_F"] / (2 ** (self.n_scales - 1))
-        L["F_Warp"] = masked_l1(resample(real_B_prev, flow), real_B, conf_ref) * o["lambda_T"]
-        L["W"] = masked_l1(weight, torch.zeros_like(weight), conf_ref) if o["no_first_img"] else torch.zeros((), device=flow.device)
+        wF, wT = o["lambda_F"] / (2 ** (self.n_scales - 1)), o["lambda_T"]
+        if o["fused_losses"]:
+            terms = [("ml1", flow, flow_ref, conf_ref, wF, 0),
+                     ("ml1", resample(real_B_prev, flow), real_B, conf_ref, wT, 1),
+                     ("ml1", fake_B, resample(fake_B_prev, flow_ref), conf_ref, wT, 3)]
+            if o["no_first_img"]:
+                terms.append(("ml1", weight, None, conf_ref, 1.0, 2))
+            out = fused_losses(terms, 4, o["compute_dtype"])
+            L["F_Flow"], L["F_Warp"], L["W"], L["G_Warp"] = out[0], out[1], out[2], out[3]
+        else:
+            L["F_Flow"] = masked_l1(flow, flow_ref, conf_ref) * wF
+            L["F_Warp"] = masked_l1(resample(real_B_prev, flow), real_B, conf_ref) * wT
+            L["W"] = masked_l1(weight, torch.zeros_like(weight), conf_ref) if o["no_first_img"] else torch.zeros((), device=flow.device)
+            L["G_Warp"] = masked_l1(fake_B, resample(fake_B_prev, flow_ref).detach(), conf_ref) * wT
         L["G_VGG"] = torch.zeros((), device=flow.device)  # VGG19 weights are not available offline (no_vgg)
         d_real, d_fake, g_gan, g_fm = self._loss_D(self.netD, torch.cat((real_A, real_B), 1), torch.cat((real_A, fake_B), 1))
-        L["G_Warp"] = masked_l1(fake_B, resample(fake_B_prev, flow_ref).detach(), conf_ref) * o["lambda_T"]
         d_real2, d_fake2, g_gan2, g_fm2 = self._loss_D(self.netD, torch.cat((real_A, real_B), 1), torch.cat((real_A, fake_B_raw), 1))
         L["D_real"], L["D_fake"] = d_real + d_real2, d_fake + d_fake2
         L["G_GAN"], L["G_GAN_Feat"] = g_gan + g_gan2, g_fm + g_fm2
