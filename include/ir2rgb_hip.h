@@ -285,6 +285,19 @@ int ir2rgb_loss_multi_fwd(const ir2rgb_loss_item *items, int count, int dtype, f
 /* Writes items[i].ga for every item that has one; gout = gradient w.r.t. out (device, fp32). */
 int ir2rgb_loss_multi_bwd(const ir2rgb_loss_item *items, int count, int dtype, const float *gout, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * torch.optim.Adam step (weight_decay 0, amsgrad off) of one optimizer in one launch; replaces the
+ * per-tensor torch kernels behind optimizer_G/D/D_T.step() (reference train_vid2vid.py:93-105).
+ *   table  : device array of { float *p; const float *g; float *m; float *v; long n; } (40 bytes each)
+ *   blocks : device array of int pairs (tensor index, chunk index): one workgroup updates elements
+ *            [chunk*E, min(n, (chunk+1)*E)) of its tensor, E = ir2rgb_adam_chunk_elems(); the caller
+ *            lists every chunk of every tensor exactly once
+ *   step   : 1-based step count (bias corrections 1 - beta^step are evaluated on the host in double)
+ * ------------------------------------------------------------------------------------------ */
+int ir2rgb_adam_chunk_elems(void);
+int ir2rgb_adam_step(const void *table, const void *blocks, int nblocks, float lr, float beta1, float beta2, float eps,
+                     int step, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

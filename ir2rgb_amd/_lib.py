@@ -72,6 +72,8 @@ PROTOTYPES = {
     "ir2rgb_loss_partial_elems": (c_int, []),
     "ir2rgb_loss_multi_fwd": (c_int, [_pitem, c_int, c_int, P, P, P]),
     "ir2rgb_loss_multi_bwd": (c_int, [_pitem, c_int, c_int, P, P]),
+    "ir2rgb_adam_chunk_elems": (c_int, []),
+    "ir2rgb_adam_step": (c_int, [P, P, c_int, c_float, c_float, c_float, c_float, c_int, P]),
 }
 
 _lib = None

@@ -158,10 +158,13 @@ def conv_wgrad(x, gy, weight_shape, spec):
 # weight gradients on a second HIP stream.  The data-gradient chain (dgrad conv -> fold -> BN
 # backward of the layer below) is the critical path of loss.backward(); the weight gradient of a
 # layer only feeds the optimizer, so it runs beside that chain and fills the CUs the chain's small
-# launches leave idle.  Only a parameter's FIRST contribution of a backward pass goes to the side
-# stream (autograd adopts it without touching it); a later contribution is accumulated in place by
-# autograd on the main stream, so it is computed there after the side stream has been joined.
-# The side stream is joined again when the backward pass ends (engine callback).
+# launches leave idle.  This is only sound for a parameter that is used ONCE per backward pass:
+# autograd then hands the tensor to AccumulateGrad untouched.  A parameter used by several nodes has
+# its contributions summed by the engine on the main stream, which knows nothing of the side stream
+# (measured: discriminator gradients, 3 uses per pass, came out wrong).  So the side stream is opt-in
+# per module tree (enable_side_wgrad: the trainer turns it on for the generators, each called once
+# per window) and never used while the parameter already holds a gradient.  The side stream is joined
+# when the backward pass ends (engine callback).
 # ---------------------------------------------------------------------------------------------
 WGRAD_SIDE_STREAM = os.environ.get("IR2RGB_WGRAD_STREAM", "1") != "0"
 _SIDE = {}
@@ -174,11 +177,20 @@ def _join_side(dev_index):
     torch.cuda.current_stream(dev_index).wait_stream(st["stream"])
 
 
-def wgrad_overlapped(param, fn, *inputs):
-    """Run ``fn()`` (a weight-gradient computation reading ``inputs``) on the side stream when that is
-    safe for ``param`` (see above), else on the current stream."""
+def enable_side_wgrad(module, enabled=True):
+    """Allow (or forbid) side-stream weight gradients for every convolution under ``module``.  The caller
+    asserts that each of these convolutions is applied once per backward pass."""
+    for m in module.modules():
+        if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+            m._ir2rgb_side_wgrad = bool(enabled)
+
+
+def wgrad_overlapped(conv, fn, *inputs):
+    """Run ``fn()`` (the weight-gradient computation of ``conv`` reading ``inputs``) on the side stream
+    when that is safe (see above), else on the current stream."""
     dev = inputs[0].device
-    if not WGRAD_SIDE_STREAM or dev.type != "cuda":
+    param = conv.weight
+    if not WGRAD_SIDE_STREAM or dev.type != "cuda" or not getattr(conv, "_ir2rgb_side_wgrad", False):
         return fn()
     st = _SIDE.get(dev.index)
     if st is None:
@@ -291,9 +303,9 @@ class ConvStageFn(Function):
                     cin = conv.in_channels
                     gwe = gwe[:, :cin * kw, :, 0].reshape(conv.out_channels, cin, kw, kh)  # [co][ci][kx][ky]
                     return gwe.permute(0, 1, 3, 2).contiguous()
-                dw = wgrad_overlapped(conv.weight, first_wgrad, xin, gy)
+                dw = wgrad_overlapped(conv, first_wgrad, xin, gy)
             else:
-                dw = wgrad_overlapped(conv.weight, lambda: conv_wgrad(xin, gy, tuple(conv.weight.shape), spec), xin, gy)
+                dw = wgrad_overlapped(conv, lambda: conv_wgrad(xin, gy, tuple(conv.weight.shape), spec), xin, gy)
         r1 = gz if ctx.has_res[0] else None
         r2 = gz if ctx.has_res[1] else None
         return dx, dw, (dbias if ctx.needs_input_grad[2] else None), dgamma, dbeta, r1, r2, None, None, None

@@ -1,0 +1,84 @@
+"""Adam over a parameter list as ONE launch per step (libir2rgb_hip.so: adam.hip).
+
+Same update as ``torch.optim.Adam(params, lr, betas, eps=1e-8)`` with weight_decay 0 and amsgrad off,
+which is what the reference builds (generator.py / discriminator.py ``torch.optim.Adam(params, lr=opt.lr,
+betas=(opt.beta1, 0.999))``).  Moments live in two flat fp32 buffers; a device table of
+{param, grad, exp_avg, exp_avg_sq, numel} rows is refreshed with the current gradient pointers before
+every step (one small asynchronous copy from pinned memory).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class FusedAdam:
+    def __init__(self, params, lr=2e-4, betas=(0.5, 0.999), eps=1e-8):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FusedAdam: no trainable parameters")
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise ValueError("FusedAdam: GPU parameters only (no CPU fallback)")
+        for p in self.params:
+            if p.dtype != torch.float32 or not p.is_contiguous() or p.device != dev:
+                raise ValueError("FusedAdam: contiguous fp32 parameters on one device")
+        self.lr, self.betas, self.eps, self.step_count = lr, betas, eps, 0
+        n = sum(p.numel() for p in self.params)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        lib = _lib.lib()
+        chunk = lib.ir2rgb_adam_chunk_elems()
+        rows = np.zeros((len(self.params), 5), dtype=np.int64)
+        blocks, off = [], 0
+        for i, p in enumerate(self.params):
+            k = p.numel()
+            rows[i] = (p.data_ptr(), 0, self.exp_avg.data_ptr() + 4 * off, self.exp_avg_sq.data_ptr() + 4 * off, k)
+            blocks += [(i, c) for c in range((k + chunk - 1) // chunk)]
+            off += k
+        # two pinned staging copies used alternately: the host may run a step ahead of the GPU, and a
+        # staging buffer is rewritten only after the asynchronous copy that last read it has completed
+        self._rows_host = [torch.from_numpy(rows.copy()).pin_memory() for _ in range(2)]
+        self._rows_np = [t.numpy() for t in self._rows_host]
+        self._copied = [None, None]
+        self._rows_dev = torch.empty_like(self._rows_host[0], device=dev)
+        self._blocks = torch.tensor(blocks, dtype=torch.int32, device=dev)
+        self._ptrs = [p.data_ptr() for p in self.params]
+        self.device = dev
+
+    def moments(self, i):
+        """(exp_avg, exp_avg_sq) views of parameter i (for tests / checkpoints)."""
+        off = sum(p.numel() for p in self.params[:i])
+        k = self.params[i].numel()
+        return self.exp_avg[off:off + k].view_as(self.params[i]), self.exp_avg_sq[off:off + k].view_as(self.params[i])
+
+    @torch.no_grad()
+    def step(self):
+        k = self.step_count & 1
+        if self._copied[k] is not None:
+            self._copied[k].synchronize()
+        rows = self._rows_np[k]
+        for i, p in enumerate(self.params):
+            g = p.grad
+            if g is None:
+                raise RuntimeError("FusedAdam.step: a parameter has no gradient (FlatGrads assigns zeros to unused ones)")
+            if g.dtype != torch.float32 or not g.is_contiguous():
+                g = p.grad = g.float().contiguous()
+            if p.data_ptr() != self._ptrs[i]:
+                raise RuntimeError("FusedAdam.step: parameter storage moved since construction")
+            rows[i, 1] = g.data_ptr()
+        self._rows_dev.copy_(self._rows_host[k], non_blocking=True)
+        if self._copied[k] is None:
+            self._copied[k] = torch.cuda.Event()
+        self._copied[k].record()
+        self.step_count += 1
+        with _lib.on_device(self.exp_avg):
+            rc = _lib.lib().ir2rgb_adam_step(ctypes.c_void_p(self._rows_dev.data_ptr()), ctypes.c_void_p(self._blocks.data_ptr()),
+                                             self._blocks.shape[0], self.lr, self.betas[0], self.betas[1], self.eps,
+                                             self.step_count, _lib.current_stream(self.exp_avg))
+        _lib.check(rc, "adam_step")
+        # the kernel wrote the parameters behind autograd's back: bump their version counters so that
+        # caches keyed on them (the packed MFMA weights of ir2rgb_amd.layers) are refreshed
+        torch.autograd.graph.increment_version(self.params)

@@ -20,8 +20,9 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
-from . import networks
+from . import autograd, networks
 from .losses import fused_losses
+from .optim import FusedAdam
 from .ext import warp_diff_norm
 
 DEFAULTS = dict(  # options/base_options.py, options/train_options.py
@@ -30,6 +31,7 @@ DEFAULTS = dict(  # options/base_options.py, options/train_options.py (SURVEY se
     feat_num=3, first_layer_dis_filters=64, num_D=2, n_layers_D=3, no_ganFeat=False, n_frames_D=3, n_scales_temporal=2,
     lr=2e-4, beta1=0.5, lambda_feat=10.0, lambda_T=10.0, lambda_F=10.0, no_first_img=False, max_frames_per_gpu=1,
     n_frames_bp=1, compute_dtype=torch.bfloat16, flownet_dtype=torch.bfloat16,
+    fused_adam=True,     # one-launch HIP Adam (ir2rgb_amd.optim); False = torch.optim.Adam(foreach=True)
     fused_losses=True,   # grouped HIP loss kernels (ir2rgb_amd.losses); False = the same terms through torch ops
 )
 
@@ -202,15 +204,22 @@ class Vid2VidTrainer:
             m.to(device).train()
             m.compute_dtype = o["compute_dtype"]
         self.flow_net = FlowNet(o["flownet_dtype"]).to(device)
+        self._side_wgrad = None          # set per window in generate(): safe only when n_load == 1
 
         g_params = [p for g in self.netG for p in g.parameters()]  # niter_fix_global = 0: all scales train
-        adam = dict(lr=o["lr"], betas=(o["beta1"], 0.999), fused=True)
+        # NOT fused=True: torch's fused Adam updates the parameters without bumping their version counters,
+        # and the packed MFMA weights (ir2rgb_amd.layers.packed_weight) are refreshed on a version change
+        adam = dict(lr=o["lr"], betas=(o["beta1"], 0.999), foreach=True)
         self.grads_G = FlatGrads(g_params)
         self.grads_D = FlatGrads(self.netD.parameters())
         self.grads_DT = [FlatGrads(d.parameters()) for d in self.netD_T]
-        self.optimizer_G = torch.optim.Adam(self.grads_G.params, **adam)
-        self.optimizer_D = torch.optim.Adam(self.grads_D.params, **adam)
-        self.optimizer_D_T = [torch.optim.Adam(g.params, **adam) for g in self.grads_DT]
+        if o["fused_adam"]:
+            make = lambda ps: FusedAdam(ps, lr=o["lr"], betas=(o["beta1"], 0.999))  # noqa: E731
+        else:
+            make = lambda ps: torch.optim.Adam(ps, **adam)  # noqa: E731
+        self.optimizer_G = make(self.grads_G.params)
+        self.optimizer_D = make(self.grads_D.params)
+        self.optimizer_D_T = [make(g.params) for g in self.grads_DT]
         self.reset_sequence()
 
     # ------------------------------------------------------------------ per-sequence state
@@ -224,6 +233,12 @@ class Vid2VidTrainer:
         (generator.py:99-123)."""
         tG, ns = self.opt["n_input_gen_frames"], self.n_scales
         n_load = real_A_all.size(1) - tG + 1
+        if self._side_wgrad != (n_load == 1):
+            # every generator is applied once per backward pass when one frame is generated per window:
+            # only then may its weight gradients run on the side stream (ir2rgb_amd.autograd)
+            self._side_wgrad = n_load == 1
+            for g in self.netG:
+                autograd.enable_side_wgrad(g, self._side_wgrad)
         first = self.fake_B_prev is None
         fake_pyr = avg_pool_pyramid(real_B_all[:, :tG - 1], ns) if first else self.fake_B_prev
         A_pyr = avg_pool_pyramid(real_A_all, ns)
