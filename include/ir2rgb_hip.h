@@ -149,10 +149,13 @@ int ir2rgb_conv2d_fwd(const ir2rgb_conv_desc *d, const void *x, const void *wpac
  * Reduces the [rows][2][C] partial sums written by ir2rgb_conv2d_fwd over `count` pixels into
  * scale = gamma*invstd and shift = beta - mean*scale, and updates running_mean / running_var
  * in place (momentum form of torch: new = (1-m)*old + m*batch, unbiased variance).  gamma, beta,
- * running_*, mean_out, invstd_out may be NULL. */
+ * running_*, mean_out, invstd_out may be NULL.  stat_updates >= 1: the momentum update is applied
+ * that many times (a forward that stands for several identical forwards of the reference, e.g.
+ * compute_loss_D evaluating netD on the same real frames twice per step, discriminator.py:154-166). */
 int ir2rgb_bn_finalize(const float *stats_partial, int rows, int C, long count, const float *gamma,
                        const float *beta, float *running_mean, float *running_var, float momentum, float eps,
-                       float *scale, float *shift, float *mean_out, float *invstd_out, void *stream);
+                       float *scale, float *shift, float *mean_out, float *invstd_out, int stat_updates,
+                       void *stream);
 
 /* y = act(x*scale[c] + shift[c]) + res1 + res2 on NHWC half tensors of npix pixels x C channels
  * (C % 8 == 0).  act: 0 none, 1 ReLU, 2 LeakyReLU(0.2).  res1/res2 may be NULL; y may alias x.

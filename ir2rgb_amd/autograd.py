@@ -12,6 +12,7 @@ data gradients, weight gradients (MFMA, transposed LDS reads), reflection fold a
 are HIP, as are the backward of the separable head convolutions and of the warp-blend.  No torch
 convolution is left on the generator / discriminator path, forward or backward.
 """
+import contextlib
 import ctypes
 import os
 
@@ -213,6 +214,32 @@ def wgrad_overlapped(conv, fn, *inputs):
 
 
 # ---------------------------------------------------------------------------------------------
+# backward flags.  A discriminator forward on generated frames serves two losses: the discriminator's
+# (gradients for the discriminator parameters only) and the generator's (gradients for the frames
+# only).  The reference runs that forward twice -- netD(fake.detach()) and netD(fake) with the result of
+# the latter never reaching optimizer_D (discriminator.py:154-166) -- although both produce the same
+# activations.  Here it runs once; which gradients a backward pass over it produces is selected by
+# flags the trainer sets on the convolution modules around each loss.backward():
+#   SKIP_PARAM_GRADS  no weight / bias / BatchNorm gradients (the generator's pass)
+#   SKIP_INPUT_GRAD   an input layer ('first' stage) returns no gradient for the image (the
+#                     discriminator's pass: nothing flows back into the generator)
+# ---------------------------------------------------------------------------------------------
+SKIP_PARAM_GRADS, SKIP_INPUT_GRAD = 1, 2
+
+
+@contextlib.contextmanager
+def backward_flags(modules, flags):
+    convs = [m for mod in modules for m in mod.modules() if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d))]
+    for m in convs:
+        m._ir2rgb_bwd = flags
+    try:
+        yield
+    finally:
+        for m in convs:
+            m._ir2rgb_bwd = 0
+
+
+# ---------------------------------------------------------------------------------------------
 # the fused stage
 # ---------------------------------------------------------------------------------------------
 class ConvStageFn(Function):
@@ -257,6 +284,9 @@ class ConvStageFn(Function):
         xin, y, scale, shift, mean, invstd = ctx.saved_tensors
         hdt = xin.dtype
         pad_fn = None
+        flags = getattr(conv, "_ir2rgb_bwd", 0)
+        want_params = not (flags & SKIP_PARAM_GRADS)
+        want_dx = ctx.needs_input_grad[0] and not (spec["first"] and (flags & SKIP_INPUT_GRAD))
         if spec.get("out_f32", False):
             # thin fp32 output (PatchGAN logits): pad the gradient to 64 channels for the MFMA adjoint
             cout = y.shape[1]
@@ -279,7 +309,7 @@ class ConvStageFn(Function):
             gy_thin = gy
             dgamma = dbeta = None
         dx = None
-        if ctx.needs_input_grad[0]:
+        if want_dx:
             if spec["first"]:
                 kh, kw = conv.kernel_size
                 sub = dict(spec, k=(kh, 1), stride=(spec["stride"][0], 1), pad=(spec["pad"][0], 0))
@@ -294,7 +324,9 @@ class ConvStageFn(Function):
                 dx = conv_dgrad(gy, conv, spec, ctx.x_shape, pad_fn)
         gy = gy_thin
         dw = None
-        if ctx.needs_input_grad[1]:
+        if not want_params:
+            dbias = dgamma = dbeta = None
+        if ctx.needs_input_grad[1] and want_params:
             if spec["first"]:
                 def first_wgrad():
                     kh, kw = conv.kernel_size

@@ -466,6 +466,58 @@ pack_weight_kernel(const float *__restrict__ w, uint16_t *__restrict__ wp, const
     }
 }
 
+// Tiled packing of a plain Conv2d weight [Cout][Cin][T] (T = kh*kw <= 9 taps in row-major order, one
+// class): a block stages the 64 co x 64 ci x T tile through LDS so that both the fp32 reads (64*T
+// contiguous floats per co) and the half writes (64 contiguous halfs per (row, tap)) are coalesced.
+//   ADJ = 0:  Wp[co][ci/64][t][ci%64]           = w[co][ci][t]            (forward operand)
+//   ADJ = 1:  Wp[ci][co/64][T-1-t][co%64]       = w[co][ci][t]            (data-gradient operand:
+//             roles of the channel axes swapped, taps flipped)
+#define PACK_MAX_T 9
+template <int DT, int ADJ>
+__global__ void __launch_bounds__(256)
+pack_tile_kernel(const float *__restrict__ w, uint16_t *__restrict__ wp, int Cout, int Cin, int T) {
+    __shared__ uint16_t tile[64 * (PACK_MAX_T * 64 + 4)];   // [64 co][T*64 + 4]: 72.5 KB, two blocks per CU
+    const int row = T * 64 + 4;
+    const int cc = blockIdx.x, cb = blockIdx.y;          // ci chunk, co block
+    const int co0 = cb * 64, ci0 = cc * 64;
+    const int q_per_row = T * 16;                        // float4 per co row
+    for (int i = threadIdx.x; i < 64 * q_per_row; i += 256) {
+        const int co_l = i / q_per_row, q = i - co_l * q_per_row;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (co0 + co_l < Cout) v = *reinterpret_cast<const float4 *>(w + ((long)(co0 + co_l) * Cin + ci0) * T + 4 * q);
+        uint2 h;
+        h.x = (uint32_t)Half<DT>::cvt(v.x) | ((uint32_t)Half<DT>::cvt(v.y) << 16);
+        h.y = (uint32_t)Half<DT>::cvt(v.z) | ((uint32_t)Half<DT>::cvt(v.w) << 16);
+        *reinterpret_cast<uint2 *>(tile + co_l * row + 4 * q) = h;     // element ci_l*T + t of the row
+    }
+    __syncthreads();
+    const int kch = ADJ ? Cout / 64 : Cin / 64;
+    for (int i = threadIdx.x; i < 64 * T * 8; i += 256) {
+        const int o8 = i & 7, rt = i >> 3;               // 8 consecutive output channels o8*8.., (row r, tap t)
+        const int r = rt / T, t = rt - r * T;
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t lo, hi;
+            if (ADJ) {   // r = ci_l, outputs run over co_l
+                lo = tile[(o8 * 8 + 2 * j) * row + r * T + t];
+                hi = tile[(o8 * 8 + 2 * j + 1) * row + r * T + t];
+            } else {     // r = co_l, outputs run over ci_l
+                lo = tile[r * row + (o8 * 8 + 2 * j) * T + t];
+                hi = tile[r * row + (o8 * 8 + 2 * j + 1) * T + t];
+            }
+            o[j] = lo | (hi << 16);
+        }
+        if (ADJ) {
+            const long dst = ((((long)(ci0 + r) * kch + cb) * T + (T - 1 - t)) * 64 + o8 * 8);
+            *reinterpret_cast<uint4 *>(wp + dst) = make_uint4(o[0], o[1], o[2], o[3]);
+        } else if (co0 + r < Cout) {
+            const long dst = ((((long)(co0 + r) * kch + cc) * T + t) * 64 + o8 * 8);
+            *reinterpret_cast<uint4 *>(wp + dst) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------------------
@@ -615,6 +667,28 @@ static int pack_impl(const ir2rgb_conv_desc *d, const float *w, void *wpacked, v
     int n = make_plan(d, plans);
     if (n < 0) return n;
     if (adjoint && d->transposed) return IR2RGB_ENOSUP;
+    // fast path: plain convolution weight, one class, all taps in row-major order, <= 9 taps
+    {
+        const PackGeom &pg = plans[0].pack;
+        const int T = d->kh * d->kw;
+        bool natural = n == 1 && !d->transposed && !pg.transposed && !pg.flip && pg.ntaps == T && T <= PACK_MAX_T;
+        for (int t = 0; natural && t < T; ++t) natural = pg.ky[t] == t / d->kw && pg.kx[t] == t % d->kw;
+        // the packed buffer of the adjoint descriptor d (Cin' = d->Cin plays the source's Cout axis)
+        const int srcCout = adjoint ? d->Cin : d->Cout, srcCin = adjoint ? d->Cout : d->Cin;
+        if (natural && srcCin % 64 == 0 && (!adjoint || srcCout % 64 == 0) && (((uintptr_t)w | (uintptr_t)wpacked) & 15) == 0) {
+            dim3 grid((unsigned)(srcCin / 64), (unsigned)((srcCout + 63) / 64));
+            uint16_t *dst = reinterpret_cast<uint16_t *>(wpacked);
+            hipStream_t s = as_stream(stream);
+            if (d->dtype == IR2RGB_BF16) {
+                if (adjoint) pack_tile_kernel<IR2RGB_BF16, 1><<<grid, 256, 0, s>>>(w, dst, srcCout, srcCin, T);
+                else pack_tile_kernel<IR2RGB_BF16, 0><<<grid, 256, 0, s>>>(w, dst, srcCout, srcCin, T);
+            } else {
+                if (adjoint) pack_tile_kernel<IR2RGB_F16, 1><<<grid, 256, 0, s>>>(w, dst, srcCout, srcCin, T);
+                else pack_tile_kernel<IR2RGB_F16, 0><<<grid, 256, 0, s>>>(w, dst, srcCout, srcCin, T);
+            }
+            return ir2rgb_launch_status();
+        }
+    }
     for (int i = 0; i < n; ++i) {
         if (adjoint) { plans[i].pack.transposed = 1; plans[i].pack.flip = 1; }
         long total = (long)d->Cout * d->Cin * plans[i].geom.ntaps;

@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(1024)
 bn_finalize_kernel(const float *__restrict__ partial, int rows, int C, double count, const float *__restrict__ gamma,
                    const float *__restrict__ beta, float *__restrict__ running_mean, float *__restrict__ running_var,
                    float momentum, float eps, float *__restrict__ scale, float *__restrict__ shift,
-                   float *__restrict__ mean_out, float *__restrict__ invstd_out) {
+                   float *__restrict__ mean_out, float *__restrict__ invstd_out, int stat_updates) {
     __shared__ double red[2][32][33];
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
@@ -55,10 +55,17 @@ bn_finalize_kernel(const float *__restrict__ partial, int rows, int C, double co
     shift[c] = b - (float)mean * sc;
     if (mean_out) mean_out[c] = (float)mean;
     if (invstd_out) invstd_out[c] = invstd;
-    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    // stat_updates > 1: this forward stands for that many identical forwards of the reference
+    if (running_mean) {
+        float r = running_mean[c];
+        for (int u = 0; u < stat_updates; ++u) r = (1.f - momentum) * r + momentum * (float)mean;
+        running_mean[c] = r;
+    }
     if (running_var) {
         double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        float r = running_var[c];
+        for (int u = 0; u < stat_updates; ++u) r = (1.f - momentum) * r + momentum * (float)unbiased;
+        running_var[c] = r;
     }
 }
 
@@ -224,11 +231,11 @@ xexpand_kernel(const float *__restrict__ in, uint4 *__restrict__ out, int Cin, i
 extern "C" int ir2rgb_bn_finalize(const float *stats_partial, int rows, int C, long count, const float *gamma,
                                   const float *beta, float *running_mean, float *running_var, float momentum,
                                   float eps, float *scale, float *shift, float *mean_out, float *invstd_out,
-                                  void *stream) {
-    if (rows < 1 || C < 1 || count < 1 || !stats_partial || !scale || !shift) return IR2RGB_EINVAL;
+                                  int stat_updates, void *stream) {
+    if (rows < 1 || C < 1 || count < 1 || !stats_partial || !scale || !shift || stat_updates < 1) return IR2RGB_EINVAL;
     bn_finalize_kernel<<<cdiv(C, 32), 1024, 0, as_stream(stream)>>>(stats_partial, rows, C, (double)count, gamma, beta,
                                                                     running_mean, running_var, momentum, eps, scale,
-                                                                    shift, mean_out, invstd_out);
+                                                                    shift, mean_out, invstd_out, stat_updates);
     return ir2rgb_launch_status();
 }
 

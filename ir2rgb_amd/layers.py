@@ -11,6 +11,7 @@ Parameters stay in the fp32 ``nn.Conv2d`` / ``nn.BatchNorm2d`` containers the st
 exposes; the half-precision packed copy the MFMA kernel streams is cached per module and
 refreshed whenever the fp32 weight's version counter moves (optimizer step, load_state_dict).
 """
+import contextlib
 import ctypes
 
 import torch
@@ -55,6 +56,21 @@ def packed_weight(mod, desc, weight=None, tag="w", adjoint=False):
 # ---------------------------------------------------------------------------------------------
 # BatchNorm pieces
 # ---------------------------------------------------------------------------------------------
+# How many identical forwards of the reference the current forward stands for (running statistics and
+# num_batches_tracked advance that many times); set with ``repeated_forward``.
+_STAT_UPDATES = 1
+
+
+@contextlib.contextmanager
+def repeated_forward(times):
+    global _STAT_UPDATES
+    old, _STAT_UPDATES = _STAT_UPDATES, int(times)
+    try:
+        yield
+    finally:
+        _STAT_UPDATES = old
+
+
 def bn_finalize(stats, count, bn, training=True):
     """-> (scale, shift, mean, invstd) fp32 [C].  Updates bn.running_* like nn.BatchNorm2d."""
     rows, _, ch = stats.shape
@@ -69,10 +85,11 @@ def bn_finalize(stats, count, bn, training=True):
         rc = _lib.lib().ir2rgb_bn_finalize(_p(stats), rows, ch, int(count), _p(bn.weight), _p(bn.bias),
                                            _p(bn.running_mean) if track else _p(None),
                                            _p(bn.running_var) if track else _p(None), float(momentum), float(bn.eps),
-                                           _p(scale), _p(shift), _p(mean), _p(invstd), _lib.current_stream(stats))
+                                           _p(scale), _p(shift), _p(mean), _p(invstd), _STAT_UPDATES,
+                                           _lib.current_stream(stats))
     _lib.check(rc, "bn_finalize")
     if track and bn.num_batches_tracked is not None:
-        _PENDING_COUNTERS.append(bn.num_batches_tracked)
+        _PENDING_COUNTERS.append((bn.num_batches_tracked, _STAT_UPDATES))
     return scale, shift, mean, invstd
 
 
@@ -83,7 +100,8 @@ def flush_bn_counters():
     """num_batches_tracked += 1 for every BatchNorm touched since the last flush -- one fused launch
     (called at the end of each generator / discriminator forward)."""
     if _PENDING_COUNTERS:
-        torch._foreach_add_(_PENDING_COUNTERS, 1)
+        for k in sorted({k for _, k in _PENDING_COUNTERS}):
+            torch._foreach_add_([t for t, kk in _PENDING_COUNTERS if kk == k], k)
         _PENDING_COUNTERS.clear()
 
 

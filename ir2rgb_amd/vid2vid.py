@@ -20,7 +20,7 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
-from . import autograd, networks
+from . import autograd, layers, networks
 from .losses import fused_losses
 from .optim import FusedAdam
 from .ext import warp_diff_norm
@@ -31,6 +31,7 @@ DEFAULTS = dict(  # options/base_options.py, options/train_options.py (SURVEY se
     feat_num=3, first_layer_dis_filters=64, num_D=2, n_layers_D=3, no_ganFeat=False, n_frames_D=3, n_scales_temporal=2,
     lr=2e-4, beta1=0.5, lambda_feat=10.0, lambda_T=10.0, lambda_F=10.0, no_first_img=False, max_frames_per_gpu=1,
     n_frames_bp=1, compute_dtype=torch.bfloat16, flownet_dtype=torch.bfloat16,
+    shared_fake_forward=True,   # one netD forward on generated frames serves the D and the G loss (autograd.backward_flags)
     fused_adam=True,     # one-launch HIP Adam (ir2rgb_amd.optim); False = torch.optim.Adam(foreach=True)
     fused_losses=True,   # grouped HIP loss kernels (ir2rgb_amd.losses); False = the same terms through torch ops
 )
@@ -286,18 +287,26 @@ class Vid2VidTrainer:
                     loss_fm = loss_fm + dw * fw * (pred_fake[i][j] - pred_real[i][j].detach()).abs().mean(dtype=torch.float32) * o["lambda_feat"]
         return loss_gan, loss_fm
 
-    def _loss_D(self, netD, real_in, fake_in):
-        """Three forwards exactly as compute_loss_D (discriminator.py:154-166)."""
-        pred_real = netD(real_in)
-        pred_fake_d = netD(fake_in.detach())
+    def _loss_D(self, netD, real_in, fake_in, pred_real=None):
+        """Three forwards exactly as compute_loss_D (discriminator.py:154-166).  ``pred_real``: the result of
+        ``netD(real_in)`` when the caller already holds it (see image_losses)."""
+        if pred_real is None:
+            pred_real = netD(real_in)
+        shared = self.opt["shared_fake_forward"]
+        if shared:
+            with layers.repeated_forward(2):
+                pred_fake_d = pred_fake = netD(fake_in)
+        else:
+            pred_fake_d = netD(fake_in.detach())
         if self.opt["fused_losses"]:
             out = fused_losses([("mse", scale[-1], 1.0, 1.0, 0) for scale in pred_real] +
                                [("mse", scale[-1], 0.0, 1.0, 1) for scale in pred_fake_d], 2, self.opt["compute_dtype"])
             loss_D_real, loss_D_fake = out[0], out[1]
         else:
             loss_D_real, loss_D_fake = gan_loss(pred_real, True), gan_loss(pred_fake_d, False)
-        with frozen(netD):
-            pred_fake = netD(fake_in)
+        if not shared:
+            with frozen(netD):
+                pred_fake = netD(fake_in)
         loss_G_GAN, loss_G_FM = self._gan_and_fm(pred_real, pred_fake)
         return loss_D_real, loss_D_fake, loss_G_GAN, loss_G_FM
 
@@ -319,8 +328,15 @@ class Vid2VidTrainer:
             L["W"] = masked_l1(weight, torch.zeros_like(weight), conf_ref) if o["no_first_img"] else torch.zeros((), device=flow.device)
             L["G_Warp"] = masked_l1(fake_B, resample(fake_B_prev, flow_ref).detach(), conf_ref) * wT
         L["G_VGG"] = torch.zeros((), device=flow.device)  # VGG19 weights are not available offline (no_vgg)
-        d_real, d_fake, g_gan, g_fm = self._loss_D(self.netD, torch.cat((real_A, real_B), 1), torch.cat((real_A, fake_B), 1))
-        d_real2, d_fake2, g_gan2, g_fm2 = self._loss_D(self.netD, torch.cat((real_A, real_B), 1), torch.cat((real_A, fake_B_raw), 1))
+        # The reference calls compute_loss_D twice (final and raw image, discriminator.py:125-131) and each call
+        # evaluates netD on the same real pair with the same weights: identical activations, so it is
+        # evaluated once here and counted twice (BatchNorm running statistics advance twice as well;
+        # reference call sites discriminator.py:134 and :143).
+        real_in = torch.cat((real_A, real_B), 1)
+        with layers.repeated_forward(2):
+            pred_real = self.netD(real_in)
+        d_real, d_fake, g_gan, g_fm = self._loss_D(self.netD, real_in, torch.cat((real_A, fake_B), 1), pred_real)
+        d_real2, d_fake2, g_gan2, g_fm2 = self._loss_D(self.netD, real_in, torch.cat((real_A, fake_B_raw), 1), pred_real)
         L["D_real"], L["D_fake"] = d_real + d_real2, d_fake + d_fake2
         L["G_GAN"], L["G_GAN_Feat"] = g_gan + g_gan2, g_fm + g_fm2
         return L
@@ -422,13 +438,21 @@ class Vid2VidTrainer:
         self.grads_D.zero()
         for gdt in self.grads_DT:
             gdt.zero()
-        loss_G.backward()
+        shared = self.opt["shared_fake_forward"]
+        d_nets = [self.netD] + self.netD_T
+        # shared discriminator forwards are walked twice: by the generator's pass (frames only) and by the
+        # discriminators' passes (parameters only); without sharing the flags are no-ops
+        # (inputs=...: the engine then runs only the nodes that lead to those parameters, so the
+        # discriminators' passes never enter the generator graph)
+        with autograd.backward_flags(d_nets if shared else [], autograd.SKIP_PARAM_GRADS):
+            loss_G.backward(retain_graph=shared, inputs=self.grads_G.params if shared else None)
         self.grads_G.all_reduce_async(self.world)
-        loss_D.backward()
-        self.grads_D.all_reduce_async(self.world)
-        for s, ld in enumerate(loss_D_T):
-            ld.backward()
-            self.grads_DT[s].all_reduce_async(self.world)
+        with autograd.backward_flags(d_nets if shared else [], autograd.SKIP_INPUT_GRAD):
+            loss_D.backward(inputs=self.grads_D.params if shared else None)
+            self.grads_D.all_reduce_async(self.world)
+            for s, ld in enumerate(loss_D_T):
+                ld.backward(inputs=self.grads_DT[s].params if shared else None)
+                self.grads_DT[s].all_reduce_async(self.world)
         self.grads_G.wait()
         self.optimizer_G.step()
         self.grads_D.wait()

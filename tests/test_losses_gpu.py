@@ -186,3 +186,36 @@ def test_optimizer_step_reaches_the_packed_weights():
         assert n_checked > 20
     for k in res[0]:
         assert abs(res[0][k] - res[1][k]) <= 5e-3 * abs(res[1][k]), (k, res[0][k], res[1][k])
+
+
+def test_shared_discriminator_forward_changes_nothing():
+    """netD on generated frames evaluated once (serving the D and the G loss through backward flags)
+    against the reference's literal three forwards per compute_loss_D: same losses, bit-identical
+    discriminator gradients, generator gradients equal up to the float atomics of the warp backward,
+    and BatchNorm running statistics advanced as by the literal sequence."""
+    from ir2rgb_amd import vid2vid as V
+    dev = _dev()
+    A, B = V.synthetic_sequence(9, 64, 128, 7, dev)
+    runs = []
+    for shared in (True, False):
+        tr = V.Vid2VidTrainer(dev, seed=0, first_layer_gen_filters=64, gen_blocks=2, shared_fake_forward=shared)
+        noop = lambda: None  # noqa: E731  keep the gradients, skip the updates
+        tr.optimizer_G.step = tr.optimizer_D.step = noop
+        for o in tr.optimizer_D_T:
+            o.step = noop
+        for w in range(7):      # the 7th window has both temporal scales active
+            out = tr.train_window(A[:, w:w + 3], B[:, w:w + 3])
+        torch.cuda.synchronize()
+        assert "D_T1" in out
+        runs.append(({k: v.item() for k, v in out.items()},
+                     [p.grad.clone() for p in tr.grads_G.params],
+                     [p.grad.clone() for g in [tr.grads_D] + tr.grads_DT for p in g.params],
+                     [b.clone() for d in [tr.netD] + tr.netD_T for b in d.buffers()]))
+    for k in runs[0][0]:
+        assert abs(runs[0][0][k] - runs[1][0][k]) <= 1e-6 * abs(runs[1][0][k]), k
+    for a, b in zip(runs[0][2], runs[1][2]):
+        assert torch.equal(a, b)
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert (a - b).norm().item() <= 1e-4 * b.norm().item() + 1e-12
+    for a, b in zip(runs[0][3], runs[1][3]):
+        assert torch.equal(a, b), "BatchNorm running statistics / counters differ"
