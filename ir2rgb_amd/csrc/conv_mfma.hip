@@ -467,21 +467,24 @@ pack_weight_kernel(const float *__restrict__ w, uint16_t *__restrict__ wp, const
 }
 
 // Tiled packing of a plain Conv2d weight [Cout][Cin][T] (T = kh*kw <= 9 taps in row-major order, one
-// class): a block stages the 64 co x 64 ci x T tile through LDS so that both the fp32 reads (64*T
-// contiguous floats per co) and the half writes (64 contiguous halfs per (row, tap)) are coalesced.
-//   ADJ = 0:  Wp[co][ci/64][t][ci%64]           = w[co][ci][t]            (forward operand)
-//   ADJ = 1:  Wp[ci][co/64][T-1-t][co%64]       = w[co][ci][t]            (data-gradient operand:
+// class).  A block stages a TCO x TCI x T tile through LDS so that both the fp32 reads (TCI*T contiguous
+// floats per co) and the half writes (64 contiguous halfs per (row, tap)) are coalesced; the tile is
+// long (64) along the axis that is contiguous in the OUTPUT and short (16) along the other, which
+// gives 1024 blocks of 18 KB for a 1024 x 1024 weight (several per CU: loads of one overlap stores of
+// another).
+//   ADJ = 0 (16 co x 64 ci):  Wp[co][ci/64][t][ci%64]       = w[co][ci][t]   (forward operand)
+//   ADJ = 1 (64 co x 16 ci):  Wp[ci][co/64][T-1-t][co%64]   = w[co][ci][t]   (data-gradient operand:
 //             roles of the channel axes swapped, taps flipped)
 #define PACK_MAX_T 9
 template <int DT, int ADJ>
 __global__ void __launch_bounds__(256)
 pack_tile_kernel(const float *__restrict__ w, uint16_t *__restrict__ wp, int Cout, int Cin, int T) {
-    __shared__ uint16_t tile[64 * (PACK_MAX_T * 64 + 4)];   // [64 co][T*64 + 4]: 72.5 KB, two blocks per CU
-    const int row = T * 64 + 4;
-    const int cc = blockIdx.x, cb = blockIdx.y;          // ci chunk, co block
-    const int co0 = cb * 64, ci0 = cc * 64;
-    const int q_per_row = T * 16;                        // float4 per co row
-    for (int i = threadIdx.x; i < 64 * q_per_row; i += 256) {
+    constexpr int TCO = ADJ ? 64 : 16, TCI = ADJ ? 16 : 64;
+    __shared__ uint16_t tile[TCO * (TCI * PACK_MAX_T + 4)];
+    const int row = TCI * T + 4;                          // halfs per co row (+4: spreads the banks)
+    const int co0 = blockIdx.y * TCO, ci0 = blockIdx.x * TCI;
+    const int q_per_row = TCI * T / 4;                    // float4 per co row
+    for (int i = threadIdx.x; i < TCO * q_per_row; i += 256) {
         const int co_l = i / q_per_row, q = i - co_l * q_per_row;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (co0 + co_l < Cout) v = *reinterpret_cast<const float4 *>(w + ((long)(co0 + co_l) * Cin + ci0) * T + 4 * q);
@@ -491,28 +494,37 @@ pack_tile_kernel(const float *__restrict__ w, uint16_t *__restrict__ wp, int Cou
         *reinterpret_cast<uint2 *>(tile + co_l * row + 4 * q) = h;     // element ci_l*T + t of the row
     }
     __syncthreads();
-    const int kch = ADJ ? Cout / 64 : Cin / 64;
-    for (int i = threadIdx.x; i < 64 * T * 8; i += 256) {
-        const int o8 = i & 7, rt = i >> 3;               // 8 consecutive output channels o8*8.., (row r, tap t)
-        const int r = rt / T, t = rt - r * T;
-        uint32_t o[4];
+    if (ADJ) {
+        // rows r = ci_l (16), each (r, t) is 64 consecutive co: 8 lanes x 16 B
+        const int kch = Cout / 64;
+        for (int i = threadIdx.x; i < TCI * T * 8; i += 256) {
+            const int o8 = i & 7, rt = i >> 3;
+            const int r = rt / T, t = rt - r * T;
+            uint32_t o[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            uint32_t lo, hi;
-            if (ADJ) {   // r = ci_l, outputs run over co_l
-                lo = tile[(o8 * 8 + 2 * j) * row + r * T + t];
-                hi = tile[(o8 * 8 + 2 * j + 1) * row + r * T + t];
-            } else {     // r = co_l, outputs run over ci_l
-                lo = tile[r * row + (o8 * 8 + 2 * j) * T + t];
-                hi = tile[r * row + (o8 * 8 + 2 * j + 1) * T + t];
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t lo = tile[(o8 * 8 + 2 * j) * row + r * T + t];
+                const uint32_t hi = tile[(o8 * 8 + 2 * j + 1) * row + r * T + t];
+                o[j] = lo | (hi << 16);
             }
-            o[j] = lo | (hi << 16);
-        }
-        if (ADJ) {
-            const long dst = ((((long)(ci0 + r) * kch + cb) * T + (T - 1 - t)) * 64 + o8 * 8);
+            const long dst = ((((long)(ci0 + r) * kch + blockIdx.y) * T + (T - 1 - t)) * 64 + o8 * 8);
             *reinterpret_cast<uint4 *>(wp + dst) = make_uint4(o[0], o[1], o[2], o[3]);
-        } else if (co0 + r < Cout) {
-            const long dst = ((((long)(co0 + r) * kch + cc) * T + t) * 64 + o8 * 8);
+        }
+    } else {
+        // rows r = co_l (16), each (r, t) is 64 consecutive ci: 8 lanes x 16 B
+        const int kch = Cin / 64;
+        for (int i = threadIdx.x; i < TCO * T * 8; i += 256) {
+            const int o8 = i & 7, rt = i >> 3;
+            const int r = rt / T, t = rt - r * T;
+            if (co0 + r >= Cout) continue;
+            uint32_t o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t lo = tile[r * row + (o8 * 8 + 2 * j) * T + t];
+                const uint32_t hi = tile[r * row + (o8 * 8 + 2 * j + 1) * T + t];
+                o[j] = lo | (hi << 16);
+            }
+            const long dst = ((((long)(co0 + r) * kch + blockIdx.x) * T + t) * 64 + o8 * 8);
             *reinterpret_cast<uint4 *>(wp + dst) = make_uint4(o[0], o[1], o[2], o[3]);
         }
     }
@@ -676,7 +688,8 @@ static int pack_impl(const ir2rgb_conv_desc *d, const float *w, void *wpacked, v
         // the packed buffer of the adjoint descriptor d (Cin' = d->Cin plays the source's Cout axis)
         const int srcCout = adjoint ? d->Cin : d->Cout, srcCin = adjoint ? d->Cout : d->Cin;
         if (natural && srcCin % 64 == 0 && (!adjoint || srcCout % 64 == 0) && (((uintptr_t)w | (uintptr_t)wpacked) & 15) == 0) {
-            dim3 grid((unsigned)(srcCin / 64), (unsigned)((srcCout + 63) / 64));
+            const int tco = adjoint ? 64 : 16, tci = adjoint ? 16 : 64;
+            dim3 grid((unsigned)(srcCin / tci), (unsigned)((srcCout + tco - 1) / tco));
             uint16_t *dst = reinterpret_cast<uint16_t *>(wpacked);
             hipStream_t s = as_stream(stream);
             if (d->dtype == IR2RGB_BF16) {

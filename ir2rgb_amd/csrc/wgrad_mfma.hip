@@ -20,6 +20,8 @@
 // per-split fp32 slabs [split][tap][a][b] with plain stores (no float atomics: they run at ~1.3 TB/s
 // chip-wide and are order-dependent); wgrad_finish sums the slabs and permutes into the torch weight
 // layout -- deterministic.  Algorithmic flops = 2 * Q * Ca * Cb * ntaps; bound: MFMA.
+#include <utility>
+
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -229,6 +231,285 @@ conv_wgrad_kernel(const uint16_t *__restrict__ U, const uint16_t *__restrict__ V
         }
 }
 
+// ----------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolutions (the residual blocks: most of the generator's weights): all nine
+// taps of a 64 (a = cout) x 64 (b = cin) tile in ONE workgroup.
+//
+// The one-tap kernel above streams 32 KB of operands per 2 MFLOP and is bound by the LDS fill rate
+// (a CU takes in ~55-90 GB/s by LDS-DMA).  The nine taps of a 3x3 kernel read the same gradient
+// pixels and input pixels that are shifted by at most one row / one column, so a K-step here is one
+// 64-pixel row segment: the gradient tile (64 px x 64 ch) plus a 3 x 66 pixel input patch with halo
+// (33 KB) feed 9 x 64 x 64 x 64 MACs = 4.7 MFLOP.  The tap (ky,kx) operand is the patch read at row
+// offset ky*66 + kx -- no extra staging.  Four waves split b (16 channels each) and share a (64):
+// 36 accumulator tiles per wave, 26 transposed LDS reads per 36 MFMAs.
+//
+// LDS rows are 128 B (64 channels = four 32-byte pairs); pair P of row r is stored at P ^ f(r),
+// f(r) = ((r>>1)&1) | ((r>>3)&1)<<1: the 8 rows {r0+0..3, r0+8..11} touched by two 16-lane groups of a
+// transposed read then fall into 8 distinct 32-byte bank windows for ANY r0, which is what lets the
+// tap offsets shift the read rows freely.
+// 512 threads: four multiplying waves and four loader waves (one of each per SIMD).
+// Four LDS stages of 36 KB (one workgroup per CU), three K-steps in flight; every loader wave issues exactly
+// nine 1-KB LDS-DMA instructions per K-step (the last three of the 36 are padding into a dummy area)
+// so the counted s_waitcnt immediates are uniform.
+// With ksplit == 1 the tile is written straight into the torch layout [a][b][3][3] (each lane owns 9
+// consecutive floats); otherwise into per-split slabs of that layout summed by wgrad_sum_kernel.
+// ----------------------------------------------------------------------------------------
+struct Wgrad9Geom {
+    int N, H, W, Ca, Cb, pad_mode;
+    int ksteps, ksplit, segs;    // segs = W / 64
+    unsigned u_bytes, v_bytes;
+};
+
+#define W9_STAGE 36864
+#define W9_NST 4
+
+template <int IMM>
+__device__ __forceinline__ s16x4 tr_read(unsigned lds_addr) {
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(IMM) : "memory");
+    return v;
+}
+
+template <int DT>
+__global__ void __launch_bounds__(512, 1)
+conv_wgrad3x3_kernel(const uint16_t *__restrict__ U, const uint16_t *__restrict__ V, float *__restrict__ D,
+                     const Wgrad9Geom g) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[W9_NST * W9_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // waves 0..3 multiply, waves 4..7 only stage: with one wave per SIMD the nine LDS-DMA issues (and their
+    // address arithmetic) of a K-step would sit in front of that wave's MFMAs; a loader partner on the
+    // same SIMD hides them.
+    const bool loader = wave8 >= 4;
+    const int wave = wave8 & 3;
+    const int ntb = g.Cb >> 6, nta = g.Ca >> 6;
+    int bid = blockIdx.x;
+    const int tb = bid % ntb; bid /= ntb;
+    const int ta = bid % nta;
+    const int split = bid / nta;
+    const int a0 = ta * 64, b0 = tb * 64;
+    const int per = (g.ksteps + g.ksplit - 1) / g.ksplit;
+    const int kbeg = split * per, kend = min(g.ksteps, kbeg + per);
+
+    // ---------------- staging: 9 LDS-DMA instructions per wave and K-step; instruction id = wave + 4*j ----------
+    // id 0..7: gradient rows id*8 + (lane>>3); id 8..32: patch rows (id-8)*8 + (lane>>3) (< 198 valid);
+    // id 33..35: padding.  Lane slot s = lane & 7 of a 128-B row holds source chunk ((s>>1) ^ f(r))*2 + (s&1).
+    const rsrc_t ru = make_rsrc(U, g.u_bytes), rv = make_rsrc(V, g.v_bytes);
+    const int rin = lane >> 3, sl = lane & 7;
+    auto fsw = [](int r) { return ((r >> 1) & 1) | (((r >> 3) & 1) << 1); };
+    unsigned u_off[2];           // byte offset inside the 64-pixel segment of U, j = 0, 1
+    // Patch row R -> (dy, dx) relative to (y, x0).  The gather offset of a lane is
+    //   base(row, x0) + L0 + [edge fixes], L0 = (dy*W + dx)*Cb*2 + channel bytes,
+    // where the fixes only apply on the image border (uniform per K-step: top / bottom row, first / last
+    // segment): reflection moves dy = -1 -> +1 (top), +1 -> -1 (bottom), dx = -1 -> +1, 64 -> 62; zero
+    // padding turns the lane off.  So a K-step costs a handful of VALU per DMA, no divisions.
+    int v_L0[7], v_fixU[7], v_fixD[7], v_fixL[7], v_fixR[7], v_edge[7];
+    bool v_dead[7];
+    const int cb2i = g.Cb * 2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = (wave + 4 * j) * 8 + rin;
+        const int chunk = (((sl >> 1) ^ fsw(r)) << 1) | (sl & 1);
+        u_off[j] = (unsigned)r * (unsigned)g.Ca * 2u + (unsigned)(a0 + chunk * 8) * 2u;
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int id = wave + 4 * (j + 2);
+        const int R = (id - 8) * 8 + rin;
+        const bool real = id < 33 && R < 198;
+        const int pr = R / 66, pxl = R - pr * 66;
+        const int chunk = (((sl >> 1) ^ fsw(R)) << 1) | (sl & 1);
+        const int dy = pr - 1, dx = pxl - 1;
+        v_dead[j] = !real;
+        v_L0[j] = (dy * g.W + dx) * cb2i + (b0 + chunk * 8) * 2;
+        v_fixU[j] = dy == -1 ? 2 * g.W * cb2i : 0;
+        v_fixD[j] = dy == 1 ? -2 * g.W * cb2i : 0;
+        v_fixL[j] = dx == -1 ? 2 * cb2i : 0;
+        v_fixR[j] = dx == 64 ? -2 * cb2i : 0;
+        v_edge[j] = (dy == -1 ? 1 : 0) | (dy == 1 ? 2 : 0) | (dx == -1 ? 4 : 0) | (dx == 64 ? 8 : 0);
+    }
+    const unsigned ca2 = (unsigned)g.Ca * 2u;
+    const bool refl = g.pad_mode != 0;
+    // (row, seg) of the next K-step to issue, advanced incrementally; row = n*H + y
+    int is_row = kbeg / g.segs, is_seg = kbeg - is_row * g.segs, is_y = is_row % g.H, is_ks = kbeg;
+    auto issue = [&](int st) {
+        unsigned char *dst = smem + st * W9_STAGE + wave * 1024;
+        const bool live = is_ks < kend;                    // uniform; dead steps still issue (zeros) to keep counts
+        const int x0 = is_seg * 64;
+        const unsigned pix = (unsigned)is_row * (unsigned)g.W + (unsigned)x0;
+        const unsigned ubase = pix * ca2;
+        const int vbase = (int)(pix * (unsigned)cb2i);
+        const bool top = is_y == 0, bot = is_y == g.H - 1, first = is_seg == 0, last = is_seg == g.segs - 1;
+        const int edge = (top ? 1 : 0) | (bot ? 2 : 0) | (first ? 4 : 0) | (last ? 8 : 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dma16(ru, live ? ubase + u_off[j] : WG_OOB, dst + 4096 * j);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int o = vbase + v_L0[j] + (top ? v_fixU[j] : 0) + (bot ? v_fixD[j] : 0) + (first ? v_fixL[j] : 0) +
+                          (last ? v_fixR[j] : 0);
+            const bool off = v_dead[j] | !live | (!refl & ((v_edge[j] & edge) != 0));
+            dma16(rv, off ? WG_OOB : (unsigned)o, dst + 4096 * (j + 2));
+        }
+        ++is_ks;
+        if (++is_seg == g.segs) {
+            is_seg = 0;
+            ++is_row;
+            if (++is_y == g.H) is_y = 0;
+        }
+    };
+
+    // ---------------- compute roles ----------------
+    const int grp = lane >> 4, l15 = lane & 15;
+    const int qd = l15 >> 2, pp = l15 & 3;
+    const int sub = (pp >> 1) * 16 + (pp & 1) * 8;
+    const int rl = 8 * grp + qd;                       // row of this lane inside a 32-row K block (h = 0)
+    int aoff[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) aoff[mi] = rl * 128 + ((mi ^ fsw(rl)) << 5) + sub;
+    int boff[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int R = (t / 3) * 66 + (t % 3) + rl + 4 * h;
+            boff[t][h] = 8192 + R * 128 + ((wave ^ fsw(R)) << 5) + sub;
+        }
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[t][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned lds_base = (unsigned)(__SIZE_TYPE__)((__attribute__((address_space(3))) unsigned char *)smem);
+
+    if (kbeg < kend) {
+        if (loader) {
+            issue(0);
+            issue(1);
+            issue(2);
+            int st = 0;
+            for (int ks = kbeg; ks < kend; ++ks) {
+                asm volatile("s_waitcnt vmcnt(18)" ::: "memory");   // step ks has landed (ks+1, ks+2 may be in flight)
+                __builtin_amdgcn_s_barrier();                         // ... and step ks-1 has been consumed
+                issue((st + 3) & 3);
+                st = (st + 1) & 3;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // drain the padding DMAs before LDS goes away
+        } else {
+            int st = 0;
+            for (int ks = kbeg; ks < kend; ++ks) {
+                __builtin_amdgcn_s_barrier();
+                // Fragment reads are inline asm: the compiler models the ds_read_tr builtin as a possible LDS
+                // write and would put s_waitcnt vmcnt(0) in front of it (draining the three K-steps of LDS-DMA
+                // in flight).  Hence the explicit lgkmcnt waits below; each names the registers it makes valid.
+                const unsigned tbase = lds_base + (unsigned)st * W9_STAGE;
+                unsigned av[4], bv[9][2];
+    #pragma unroll
+                for (int mi = 0; mi < 4; ++mi) av[mi] = tbase + (unsigned)aoff[mi];
+    #pragma unroll
+                for (int t = 0; t < 9; ++t) { bv[t][0] = tbase + (unsigned)boff[t][0]; bv[t][1] = tbase + (unsigned)boff[t][1]; }
+                // 18 fragment steps s = kk*9 + tap, B fragments fetched three steps ahead (LDS latency is
+                // ~2 steps of 4 MFMAs), the A fragments of the second half fetched during step 5.
+                s16x4 alo[2][4], ahi[2][4], blo[4], bhi[4];
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    alo[0][mi] = tr_read<0>(av[mi]);
+                    ahi[0][mi] = tr_read<512>(av[mi]);
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    blo[q] = tr_read<0>(bv[q][0]);
+                    bhi[q] = tr_read<0>(bv[q][1]);
+                }
+                auto step = [&]<int S>(std::integral_constant<int, S>) {
+                    constexpr int KK = S / 9, T = S % 9, cur = S & 3;
+                    if constexpr (S == 5) {
+#pragma unroll
+                        for (int mi = 0; mi < 4; ++mi) {
+                            alo[1][mi] = tr_read<4096>(av[mi]);
+                            ahi[1][mi] = tr_read<4096 + 512>(av[mi]);
+                        }
+                    }
+                    if constexpr (S + 3 < 18) {
+                        constexpr int S3 = S + 3;
+                        blo[S3 & 3] = tr_read<(S3 / 9) * 4096>(bv[S3 % 9][0]);
+                        bhi[S3 & 3] = tr_read<(S3 / 9) * 4096>(bv[S3 % 9][1]);
+                    }
+                    // LDS reads issued after B(S): B(S+1..S+3), plus the 8 reads of the second A set in steps 5..8
+                    constexpr int after = 2 * ((S + 3 < 18 ? 3 : 17 - S)) + ((S >= 5 && S <= 8) ? 8 : 0);
+                    if constexpr (T == 0)
+                        asm volatile("s_waitcnt lgkmcnt(%10)"
+                                     : "+v"(alo[KK][0]), "+v"(ahi[KK][0]), "+v"(alo[KK][1]), "+v"(ahi[KK][1]), "+v"(alo[KK][2]),
+                                       "+v"(ahi[KK][2]), "+v"(alo[KK][3]), "+v"(ahi[KK][3]), "+v"(blo[cur]), "+v"(bhi[cur])
+                                     : "n"(after)
+                                     : "memory");
+                    else
+                        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(blo[cur]), "+v"(bhi[cur]) : "n"(after) : "memory");
+                    const s16x8 b = (s16x8){blo[cur][0], blo[cur][1], blo[cur][2], blo[cur][3],
+                                            bhi[cur][0], bhi[cur][1], bhi[cur][2], bhi[cur][3]};
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) {
+                        const s16x8 a = (s16x8){alo[KK][mi][0], alo[KK][mi][1], alo[KK][mi][2], alo[KK][mi][3],
+                                                ahi[KK][mi][0], ahi[KK][mi][1], ahi[KK][mi][2], ahi[KK][mi][3]};
+                        acc[T][mi] = Mfma<DT>::run(a, b, acc[T][mi]);
+                    }
+                };
+                [&]<int... Ss>(std::integer_sequence<int, Ss...>) { (step(std::integral_constant<int, Ss>{}), ...); }
+                (std::make_integer_sequence<int, 18>{});
+                st = (st + 1) & 3;
+            }
+        }
+    }
+    if (loader) return;
+
+    // ---------------- epilogue: [a][b][tap], 9 consecutive floats per (a, b) ----------------
+    float *Dt = D + (long)split * 9 * g.Ca * g.Cb;
+    const int b = b0 + wave * 16 + l15;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int a = a0 + mi * 16 + grp * 4 + r;
+            float *o = Dt + ((long)a * g.Cb + b) * 9;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) o[t] = acc[t][mi][r];
+        }
+}
+
+// out[i] = sum_split D[split][i]   (slabs already in the torch layout)
+__global__ void __launch_bounds__(256)
+wgrad_sum_kernel(const float4 *__restrict__ D, float4 *__restrict__ out, long n4, int nsplit) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 s = D[i];
+        for (int k = 1; k < nsplit; ++k) {
+            const float4 v = D[k * n4 + i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        out[i] = s;
+    }
+}
+
+static bool plan9(const ir2rgb_conv_desc *d, Wgrad9Geom *g) {
+    if (d->transposed || d->kh != 3 || d->kw != 3 || d->stride_h != 1 || d->stride_w != 1 || d->pad_h != 1 || d->pad_w != 1)
+        return false;
+    if (d->Hout != d->Hin || d->Wout != d->Win || (d->Win % 64) || (d->Cin % 64) || (d->Cout % 64) || d->Hin < 2) return false;
+    const long Q = (long)d->N * d->Hin * d->Win;
+    if (Q * d->Cout * 2 >= (1L << 31) || Q * d->Cin * 2 >= (1L << 31)) return false;
+    *g = Wgrad9Geom{};
+    g->N = d->N; g->H = d->Hin; g->W = d->Win; g->Ca = d->Cout; g->Cb = d->Cin; g->pad_mode = d->pad_mode;
+    g->segs = d->Win / 64;
+    g->ksteps = (int)(Q / 64);
+    g->u_bytes = (unsigned)(Q * d->Cout * 2); g->v_bytes = (unsigned)(Q * d->Cin * 2);
+    // one workgroup per CU: split K until ~256 workgroups exist, keeping >= 8 K-steps per split
+    const long tiles = (long)(d->Cout / 64) * (d->Cin / 64);
+    long ks = (256 + tiles - 1) / tiles;
+    if (ks > g->ksteps / 8) ks = g->ksteps / 8;
+    if (ks < 1) ks = 1;
+    if (ks > 256) ks = 256;
+    g->ksplit = (int)ks;
+    return true;
+}
+
 // out[a][b][tap] = sum_split D[split][tap][a][b]   (torch weight layout [Ca][Cb][kh][kw], fp32)
 __global__ void __launch_bounds__(256)
 wgrad_finish_kernel(const float *__restrict__ D, float *__restrict__ out, int Ca, int Cb, int ntaps, int nsplit,
@@ -285,10 +566,18 @@ static int plan(const ir2rgb_conv_desc *d, WgradGeom *g) {
     return IR2RGB_OK;
 }
 
+static bool use_wgrad9() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("IR2RGB_WGRAD9"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
+
 extern "C" long ir2rgb_conv2d_wgrad_workspace_elems(const ir2rgb_conv_desc *d) {
     WgradGeom g;
     int rc = plan(d, &g);
     if (rc) return rc;
+    Wgrad9Geom g9;
+    if (use_wgrad9() && plan9(d, &g9)) return g9.ksplit > 1 ? (long)g9.ksplit * 9 * g9.Ca * g9.Cb : 4;
     return (long)g.ksplit * d->kh * d->kw * g.Ca * g.Cb;
 }
 
@@ -301,6 +590,17 @@ extern "C" int ir2rgb_conv2d_wgrad(const ir2rgb_conv_desc *d, const void *x, con
     hipStream_t s = as_stream(stream);
     const int ntaps = d->kh * d->kw;
     const long elems = (long)ntaps * g.Ca * g.Cb;
+    Wgrad9Geom g9;
+    if (use_wgrad9() && plan9(d, &g9)) {
+        if (((uintptr_t)dw | (uintptr_t)workspace) & 15) return IR2RGB_EALIGN;
+        float *dst = g9.ksplit > 1 ? workspace : dw;
+        const unsigned grid9 = (unsigned)((long)g9.ksplit * (g9.Ca / 64) * (g9.Cb / 64));
+        if (d->dtype == IR2RGB_BF16) conv_wgrad3x3_kernel<IR2RGB_BF16><<<grid9, 512, 0, s>>>((const uint16_t *)gy, (const uint16_t *)x, dst, g9);
+        else conv_wgrad3x3_kernel<IR2RGB_F16><<<grid9, 512, 0, s>>>((const uint16_t *)gy, (const uint16_t *)x, dst, g9);
+        if (g9.ksplit > 1)
+            wgrad_sum_kernel<<<stream_grid(elems / 4, 256), 256, 0, s>>>((const float4 *)workspace, (float4 *)dw, elems / 4, g9.ksplit);
+        return ir2rgb_launch_status();
+    }
     const uint16_t *U = (const uint16_t *)(d->transposed ? x : gy), *V = (const uint16_t *)(d->transposed ? gy : x);
     const unsigned grid = (unsigned)((long)g.ksplit * ntaps * ((g.Ca + 127) / 128) * ((g.Cb + 127) / 128));
     if (d->dtype == IR2RGB_BF16) conv_wgrad_kernel<IR2RGB_BF16><<<grid, 256, 0, s>>>(U, V, workspace, g);

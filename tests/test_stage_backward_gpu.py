@@ -165,7 +165,10 @@ def test_fold_reflect_and_xexpand_adjoints(dev):
     (64, 33, 47, 64, 4, 2, 2, 0, False, 0),       # discriminator, odd sizes
     (128, 12, 20, 64, 3, 2, 1, 0, True, 1),       # transposed
     (64, 40, 72, 256, 7, 1, 3, 1, False, 0),      # 49 taps
-    (1024, 32, 64, 1024, 3, 1, 1, 1, False, 0),   # bottleneck of the 256x512 generator: no split-K remainder
+    (1024, 32, 64, 1024, 3, 1, 1, 1, False, 0),   # bottleneck of the 256x512 generator: nine-tap kernel, no split
+    (64, 8, 128, 64, 3, 1, 1, 0, False, 0),       # nine-tap kernel, zero padding, two segments per row, split-K
+    (128, 5, 64, 192, 3, 1, 1, 0, False, 0),      # nine-tap kernel, 3 x 2 tiles, odd row count
+    (128, 6, 192, 64, 3, 1, 1, 1, False, 0),      # nine-tap kernel, reflect, three segments per row
 ])
 def test_wgrad_kernel_vs_torch(dev, dtype, case):
     """MFMA weight-gradient kernel alone (transposed LDS reads, split-K atomics) vs torch's fp32
