@@ -128,12 +128,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    def traffic_of(key):
+        """HBM-side bytes per launch from the committed PMC passes (profiles/r01_dominant_conv_traffic.json); None
+        for a shape they do not cover.  (PMC counters cannot be collected inside this process.)"""
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_dominant_conv_traffic.json")) as f:
+                return json.load(f)["shapes"].get(",".join(str(int(v)) for v in key))
+        except OSError:
+            return None
+
     # ---- roofline of the dominant kernel: HIP events around each of its launches inside the timed region
     tot, n_launch, flops = prof[dominant]
     avg = tot / n_launch
     achieved = flops / avg / 1e12
     roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": None,  # PMC passes cover the 64x128 hot shape only: profiles/r01_conv_hot_pmc_summary.txt
+                "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic_of(dominant),
                 "kernel": "conv_igemm_kernel (MFMA implicit GEMM)",
                 "shape": dict(zip(("Cin", "Hin", "Win", "Cout", "kh", "kw", "stride", "reflect", "transposed"), dominant)),
                 "launches": n_launch, "avg_us": round(avg * 1e6, 1), "flops_per_launch": flops,
