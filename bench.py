@@ -36,6 +36,19 @@ H, W = 512, 1024
 PREROLL = 7           # windows until both temporal discriminator scales are active (steady state)
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota when one is set
+    (os.cpu_count() reports the whole host; 256 threads on a 16-CPU share ran the port 15x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(threads):
     """Plain-torch fp32 port of the 2-scale generator forward on the host, one frame (bounded sample)."""
     from ir2rgb_amd import networks as N
@@ -190,7 +203,7 @@ def main():
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+            line["cpu_baseline"] = cpu_baseline(usable_cpus())
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
