@@ -113,10 +113,20 @@ __device__ __forceinline__ int reflect(int v, int n) {
 // TP = 128: 2-stage ring (64 KB) and TP = 64: 3-stage ring (72 KB): two workgroups per CU (4 waves per
 // SIMD, <= 128 VGPRs), so one workgroup's prologue / epilogue / barrier stalls hide under the other's
 // MFMA work -- the configuration for short-K layers and for tile counts just above the CU count.
+template <int TP> struct ConvTile {
+    static constexpr int TC = 128;
+    static constexpr int STAGE = (TC + TP) * 128;   // bytes per stage
+    static constexpr int NSTAGE = TP == 128 ? 2 : 3;
+    static constexpr int LDS = NSTAGE * STAGE;
+};
+
+// The kernel body; `block` is the workgroup's index inside its launch (or inside its class of a
+// multi-class launch) and `smem` the workgroup's LDS ring (ConvTile<TP>::LDS bytes, 1024-aligned).
 template <int DT, int TP, int NTY, int NTX>
-__global__ void __launch_bounds__(512, (TP == 256 ? 2 : 4))
-conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Wp, const float *__restrict__ bias,
-                  uint16_t *__restrict__ Y, float *__restrict__ stats_partial, const ConvGeom g) {
+__device__ __forceinline__ void
+conv_igemm_body(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Wp, const float *__restrict__ bias,
+                uint16_t *__restrict__ Y, float *__restrict__ stats_partial, const ConvGeom &g, const int block,
+                unsigned char *const smem) {
     constexpr int TC = 128;
     constexpr int NI = TP / 64;            // 16-pixel MFMA tiles per wave along pixels
     constexpr int WROWS = TC / 64;         // weight rows staged per thread per K-step
@@ -130,7 +140,7 @@ conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W
     typedef Half<DT> H;
     typedef typename H::frag frag;
 
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTAGE * STAGE];
+    static_assert(NSTAGE * STAGE == ConvTile<TP>::LDS, "LDS ring size");
 
     const int tid = threadIdx.x, lane = tid & 63;
     // wave index as an SGPR: keeps the LDS-DMA destination (M0) provably wave-uniform, so hipcc
@@ -148,7 +158,8 @@ conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W
     // fetched 8 times).
     int tile;
     {
-        const int nwg = npt * nct, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        const int nwg = npt * nct, b = block, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        if (b >= nwg) return;   // padding workgroups of a multi-class launch (workgroup-uniform)
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     }
     int pt, ct;
@@ -443,6 +454,45 @@ conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W
     }
 }
 
+template <int DT, int TP, int NTY, int NTX>
+__global__ void __launch_bounds__(512, (TP == 256 ? 2 : 4))
+conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Wp, const float *__restrict__ bias,
+                  uint16_t *__restrict__ Y, float *__restrict__ stats_partial, const ConvGeom g) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[ConvTile<TP>::LDS];
+    conv_igemm_body<DT, TP, NTY, NTX>(X, Wp, bias, Y, stats_partial, g, (int)blockIdx.x, smem);
+}
+
+// All sub-pixel classes of a stride-2 transposed convolution (or of the data gradient of a stride-2
+// convolution) in ONE launch.  Launched class by class, each class fills only part of the chip (e.g.
+// 128 workgroups for 1024->512 @64x128) and the four launches run back to back; here the classes'
+// workgroups share the grid, longest K loop first.  Every class starts at a multiple of 8 workgroups
+// so the XCD of a workgroup is still (class-local index) & 7.
+struct ConvClasses {
+    ConvGeom g[4];
+    long w_off[4];     // element offset of the class's packed weights
+    int first[5];      // first workgroup of class c (multiples of 8); first[n] = grid size
+    int n;
+};
+
+template <int DT, int TP>
+__global__ void __launch_bounds__(512, (TP == 256 ? 2 : 4))
+conv_igemm_classes_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Wp,
+                          const float *__restrict__ bias, uint16_t *__restrict__ Y,
+                          float *__restrict__ stats_partial, const ConvClasses cs) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[ConvTile<TP>::LDS];
+    int c = 0;
+    while (c + 1 < cs.n && (int)blockIdx.x >= cs.first[c + 1]) ++c;   // workgroup-uniform
+    const ConvGeom &g = cs.g[c];
+    const uint16_t *wp = Wp + cs.w_off[c];
+    const int b = (int)blockIdx.x - cs.first[c];
+    const int nty = g.ntaps / g.ntx;
+    if (nty == 2 && g.ntx == 2)      conv_igemm_body<DT, TP, 2, 2>(X, wp, bias, Y, stats_partial, g, b, smem);
+    else if (nty == 2 && g.ntx == 1) conv_igemm_body<DT, TP, 2, 1>(X, wp, bias, Y, stats_partial, g, b, smem);
+    else if (nty == 1 && g.ntx == 2) conv_igemm_body<DT, TP, 1, 2>(X, wp, bias, Y, stats_partial, g, b, smem);
+    else if (nty == 1 && g.ntx == 1) conv_igemm_body<DT, TP, 1, 1>(X, wp, bias, Y, stats_partial, g, b, smem);
+    else                             conv_igemm_body<DT, TP, 0, 0>(X, wp, bias, Y, stats_partial, g, b, smem);
+}
+
 // ----------------------------------------------------------------------------------------
 // weight packing: torch layout (fp32) -> Wp[class][Cout][Cin/64][ntaps][64] (half)
 //   Conv2d          weight [Cout][Cin][kh][kw]
@@ -545,7 +595,14 @@ struct ClassPlan {
     PackGeom pack;
     long w_offset;  // element offset of this class in the packed weight buffer
     int npt;        // pixel tiles (TP chosen at plan time)
+    int tp;         // pixels per tile: 256 / 128 / 64
 };
+
+static bool merge_classes() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("IR2RGB_CONV_MERGE"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
 
 static int conv_variant() {
     static int v = -1;
@@ -658,8 +715,25 @@ static int make_plan(const ir2rgb_conv_desc *d, ClassPlan plans[4]) {
             const long x_used = (long)g.N * g.Hin * g.Win * g.Cin * 2;
             g.cout_major = force >= 0 ? force : (wb > x_used ? 1 : 0);
         }
+    }
+    // pixel-tile size: per class, or -- when the classes share one launch -- one size for all of them chosen
+    // from the total tile count and the longest K loop
+    int tp_all = 0;
+    if (ncls > 1 && merge_classes()) {
+        long p_all = 0;
+        int ks_max = 0;
+        for (int i = 0; i < ncls; ++i) {
+            const ConvGeom &g = plans[i].geom;
+            p_all += (long)g.N * g.Hsub * g.Wsub;
+            ks_max = g.kchunks * g.ntaps > ks_max ? g.kchunks * g.ntaps : ks_max;
+        }
+        tp_all = tile_pixels(p_all, plans[0].geom.Cout, ks_max);
+    }
+    for (int i = 0; i < ncls; ++i) {
+        ConvGeom &g = plans[i].geom;
         long P = (long)g.N * g.Hsub * g.Wsub;
-        int tp = tile_pixels(P, g.Cout, g.kchunks * g.ntaps);
+        int tp = tp_all ? tp_all : tile_pixels(P, g.Cout, g.kchunks * g.ntaps);
+        plans[i].tp = tp;
         plans[i].npt = (int)((P + tp - 1) / tp);
         g.stats_row0 = row0;
         row0 += plans[i].npt;
@@ -751,8 +825,7 @@ template <int DT>
 static void launch_conv(const ClassPlan &c, const uint16_t *x, const uint16_t *wp, const float *bias, uint16_t *y,
                         float *stats, hipStream_t s) {
     const ConvGeom &g = c.geom;
-    const long P = (long)g.N * g.Hsub * g.Wsub;
-    const int tp = tile_pixels(P, g.Cout, g.kchunks * g.ntaps);
+    const int tp = c.tp;
     const int nct = (g.Cout + 127) / 128;
     const unsigned grid = (unsigned)(c.npt * nct);
     const int nty = g.ntaps / g.ntx;
@@ -761,6 +834,11 @@ static void launch_conv(const ClassPlan &c, const uint16_t *x, const uint16_t *w
     else if (nty == 7 && g.ntx == 1) launch_conv_taps<DT, 7, 1>(c, tp, grid, x, wp, bias, y, stats, s);
     else if (nty == 1 && g.ntx == 7) launch_conv_taps<DT, 1, 7>(c, tp, grid, x, wp, bias, y, stats, s);
     else if (nty == 4 && g.ntx == 1) launch_conv_taps<DT, 4, 1>(c, tp, grid, x, wp, bias, y, stats, s);
+    // sub-pixel classes of the stride-2 transposed convolutions (3x3: 1x1, 1x2, 2x1, 2x2 taps; 4x4: 2x2)
+    else if (nty == 2 && g.ntx == 2) launch_conv_taps<DT, 2, 2>(c, tp, grid, x, wp, bias, y, stats, s);
+    else if (nty == 2 && g.ntx == 1) launch_conv_taps<DT, 2, 1>(c, tp, grid, x, wp, bias, y, stats, s);
+    else if (nty == 1 && g.ntx == 2) launch_conv_taps<DT, 1, 2>(c, tp, grid, x, wp, bias, y, stats, s);
+    else if (nty == 1 && g.ntx == 1) launch_conv_taps<DT, 1, 1>(c, tp, grid, x, wp, bias, y, stats, s);
     else                             launch_conv_taps<DT, 0, 0>(c, tp, grid, x, wp, bias, y, stats, s);
 }
 
@@ -770,6 +848,39 @@ extern "C" int ir2rgb_conv2d_fwd(const ir2rgb_conv_desc *d, const void *x, const
     int n = make_plan(d, plans);
     if (n < 0) return n;
     if ((((uintptr_t)x | (uintptr_t)wpacked | (uintptr_t)y) & 15) != 0) return IR2RGB_EALIGN;
+    if (n > 1 && merge_classes()) {
+        // one launch for all classes: same pixel-tile size for all of them (plans were made with it)
+        ConvClasses cs;
+        int order[4] = {0, 1, 2, 3};
+        for (int i = 0; i < n; ++i)           // longest K loop first
+            for (int j = i + 1; j < n; ++j)
+                if (plans[order[j]].geom.ntaps > plans[order[i]].geom.ntaps) { int t = order[i]; order[i] = order[j]; order[j] = t; }
+        int first = 0;
+        for (int i = 0; i < n; ++i) {
+            const ClassPlan &c = plans[order[i]];
+            cs.g[i] = c.geom;
+            cs.w_off[i] = c.w_offset;
+            cs.first[i] = first;
+            const int nwg = c.npt * ((c.geom.Cout + 127) / 128);
+            first += (nwg + 7) & ~7;
+        }
+        cs.first[n] = first;
+        cs.n = n;
+        const int tp = plans[0].tp;
+        hipStream_t s = as_stream(stream);
+        const uint16_t *X = (const uint16_t *)x, *W = (const uint16_t *)wpacked;
+        uint16_t *Yp = (uint16_t *)y;
+        if (d->dtype == IR2RGB_BF16) {
+            if (tp == 256) conv_igemm_classes_kernel<IR2RGB_BF16, 256><<<first, 512, 0, s>>>(X, W, bias, Yp, stats_partial, cs);
+            else if (tp == 128) conv_igemm_classes_kernel<IR2RGB_BF16, 128><<<first, 512, 0, s>>>(X, W, bias, Yp, stats_partial, cs);
+            else conv_igemm_classes_kernel<IR2RGB_BF16, 64><<<first, 512, 0, s>>>(X, W, bias, Yp, stats_partial, cs);
+        } else {
+            if (tp == 256) conv_igemm_classes_kernel<IR2RGB_F16, 256><<<first, 512, 0, s>>>(X, W, bias, Yp, stats_partial, cs);
+            else if (tp == 128) conv_igemm_classes_kernel<IR2RGB_F16, 128><<<first, 512, 0, s>>>(X, W, bias, Yp, stats_partial, cs);
+            else conv_igemm_classes_kernel<IR2RGB_F16, 64><<<first, 512, 0, s>>>(X, W, bias, Yp, stats_partial, cs);
+        }
+        return ir2rgb_launch_status();
+    }
     for (int i = 0; i < n; ++i) {
         const uint16_t *wp = reinterpret_cast<const uint16_t *>(wpacked) + plans[i].w_offset;
         if (d->dtype == IR2RGB_BF16)
