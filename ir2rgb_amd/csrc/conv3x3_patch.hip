@@ -1,0 +1,355 @@
+// conv3x3_patch.hip -- 3x3 / stride-1 convolutions with many input channels (the residual blocks:
+// 84 % of the generator's forward flops) as an implicit GEMM whose activation operand is staged ONCE
+// per channel slice instead of once per tap.
+//
+// conv_igemm_kernel (conv_mfma.hip) stages, for every (tap, 64-channel slice), a fresh im2col tile of the
+// pixels next to the weight tile: 48 one-KB LDS-DMA instructions per 256 MFMAs at its largest tile, 24
+// per 64 at its smallest -- the K loop of those layers is bound by DMA issue + barrier cadence, not by
+// the matrix cores (profiles/r01_dominant_kernels_pmc_summary.txt).  The nine taps of a 3x3 kernel read
+// the same pixels shifted by at most one row / column, so here a workgroup owns a 2 x TW pixel tile and
+// keeps a haloed 4 x (TW+2) pixel patch of a 32-channel slice in LDS; the tap (ky,kx) operand of pixel
+// (ty,tx) is simply patch entry (ty+ky, tx+kx).  Per 32-channel slice the patch is staged once (one
+// row pair with the ky = 0 step, one further row with each of the ky = 1, 2 steps) and only the
+// weights change per step: 42+33+33 DMA instructions per 288 MFMAs x 4 waves at the 2x128 px x 128
+// cout tile (1 : 10.7 against 1 : 5.3).
+//
+// LDS rows are 64 B (32 channels); 16-byte position s of row R holds source chunk s ^ ((R>>2)&3), which makes
+// the eight consecutive rows a ds_read_b128 serves together hit eight distinct bank windows for any row
+// offset (measured without the swizzle: 2-way conflicts); every fragment address is a per-lane base + a
+// compile-time immediate.  K-step = (32-channel slice, ky): three taps, MFMA K = 32.
+// Waves: NCW multiply (MI = 4 x NI accumulator tiles each; two per SIMD at the large tile so that one
+// wave's LDS latency and barrier wait hide under the other's MFMAs), NLW only stage (pure LDS-DMA issue: per-lane
+// gather offsets are constants of the workgroup's tile, the slice offset rides in an SGPR); one
+// s_barrier and one counted vmcnt per K-step; weights in an NSTW-stage ring, the patch double-buffered.
+// Epilogue: bias, LeakyReLU, per-tile BatchNorm partial sums (same [tiles][2][Cout] contract as
+// conv_igemm_kernel), half stores of 4 consecutive couts per lane.
+#include <utility>
+
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 p3_bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 p3_f16x8;
+typedef __attribute__((ext_vector_type(4))) float p3_f32x4;
+typedef __attribute__((address_space(3))) void *p3_lptr_t;
+typedef __amdgpu_buffer_rsrc_t p3_rsrc_t;
+#define P3_OOB 0x80000000u
+
+template <int DT> struct P3Half;
+template <> struct P3Half<IR2RGB_BF16> {
+    typedef p3_bf16x8 frag;
+    static __device__ __forceinline__ p3_f32x4 mfma(frag a, frag b, p3_f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ uint16_t cvt(float f) { __bf16 h = (__bf16)f; return __builtin_bit_cast(uint16_t, h); }
+};
+template <> struct P3Half<IR2RGB_F16> {
+    typedef p3_f16x8 frag;
+    static __device__ __forceinline__ p3_f32x4 mfma(frag a, frag b, p3_f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ uint16_t cvt(float f) { _Float16 h = (_Float16)f; return __builtin_bit_cast(uint16_t, h); }
+};
+
+struct P3Geom {
+    int N, H, W, Ho, Wo, Cin, Cout;   // input / output extents
+    int pad, pad_mode, act;
+    int ldx, ci_off, ldy, co_off;
+    int stats_row0, nty, ntx;         // pixel tiles per image: nty x ntx
+    int cout_major, kchunks;
+    unsigned x_bytes, w_bytes;
+};
+
+__device__ __forceinline__ int p3_reflect(int v, int n) {
+    v = v < 0 ? -v : v;
+    return v >= n ? 2 * n - 2 - v : v;
+}
+
+template <int TW, int TCO, int NCW, int NLW> struct P3Cfg {
+    static constexpr int TR = 2, NPX = TR * TW;
+    static constexpr int PWP = ((TW + 2 + 15) / 16) * 16;   // patch row pitch in entries (80 | 144)
+    static constexpr int PROWI = PWP / 16;                   // DMA instructions per patch row
+    static constexpr int NW = 3 * TCO / 16;                  // DMA instructions for the weights of one K-step
+    static constexpr int WST = 3 * TCO * 64;                 // bytes per weight stage
+    static constexpr int PBUF = 4 * PWP * 64;                // bytes per patch buffer
+    static constexpr int NSTW = (TW == 128 && TCO == 128) ? 3 : 4;
+    static constexpr int AHEAD = NSTW - 1;
+    static constexpr int WM = TCO / 64, WN = NCW / WM, PXW = NPX / WN, NI = PXW / 16;
+    static constexpr int LDS = NSTW * WST + 2 * PBUF + 1024;
+    static constexpr int np(int ky) { return ky == 0 ? 2 * PROWI : PROWI; }
+    static constexpr int nl(int ky) { return (NW + np(ky) + NLW - 1) / NLW; }     // DMA instructions per loader wave
+    static constexpr int NLMAX = nl(0);
+    // DMA instructions a loader wave may leave in flight while step (phase ky) is consumed: the steps staged after it
+    static constexpr int out(int ky) {
+        int s = 0;
+        for (int d = 1; d < AHEAD; ++d) s += nl((ky + d) % 3);
+        return s;
+    }
+};
+
+template <int DT, int TW, int TCO, int NCW, int NLW>
+__global__ void __launch_bounds__((NCW + NLW) * 64, 1)
+conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Wp, const float *__restrict__ bias,
+                     uint16_t *__restrict__ Y, float *__restrict__ stats_partial, const P3Geom g) {
+    typedef P3Cfg<TW, TCO, NCW, NLW> C;
+    typedef P3Half<DT> Hf;
+    typedef typename Hf::frag frag;
+    constexpr int NI = C::NI, MI = 4;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[C::LDS];
+    unsigned char *const wring = smem, *const pbufs = smem + C::NSTW * C::WST, *const dummy = pbufs + 2 * C::PBUF;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave >= NCW;
+
+    // ---- tile of this workgroup (XCD-aware ids as in conv_igemm_kernel) ----
+    const int npt = g.N * g.nty * g.ntx, nct = g.Cout / TCO;
+    int tile;
+    {
+        const int nwg = npt * nct, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    int pt, ct;
+    if (g.cout_major) { ct = tile / npt; pt = tile - ct * npt; }
+    else              { pt = tile / nct; ct = tile - pt * nct; }
+    const int txi = pt % g.ntx, tyi = (pt / g.ntx) % g.nty, n = pt / (g.ntx * g.nty);
+    const int y0 = tyi * C::TR, x0 = txi * TW;
+    const int NK = g.kchunks * 2 * 3;   // K-steps: (64-channel chunk, half, ky)
+
+    p3_f32x4 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (p3_f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (loader) {
+        // =============================== staging waves ===============================
+        const int lw = wave - NCW;
+        const p3_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(Wp), 0, (int)g.w_bytes, 0x00020000);
+        const p3_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(X), 0, (int)g.x_bytes, 0x00020000);
+        const int row16 = lane >> 2;
+        // per (phase ky, slot j): instruction id = lw + NLW*j -> weights (id < NW), patch, or padding
+        unsigned voff[3][C::NLMAX];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int j = 0; j < C::NLMAX; ++j) {
+                const int id = lw + NLW * j;
+                unsigned v = P3_OOB;
+                if (j < C::nl(ky)) {
+                    // LDS slot (row R, 16-byte position s) holds source chunk s ^ ((R >> 2) & 3): eight consecutive
+                    // 64-byte rows read at one logical chunk then fall into eight distinct 16-byte bank windows
+                    // (rows R and R+4 share a 256-byte bank line).  R & 15 == row16 in every region.
+                    const int chunk = (lane & 3) ^ ((row16 >> 2) & 3);
+                    if (id < C::NW) {
+                        const int row = id * 16 + row16, kx = row / TCO, col = row - kx * TCO;
+                        const int co = ct * TCO + col;
+                        v = (unsigned)((((long)co * g.kchunks) * 9 + kx) * 128 + chunk * 16);
+                    } else if (id < C::NW + C::np(ky)) {
+                        const int q = id - C::NW;
+                        const int pr = ky == 0 ? q / C::PROWI : ky + 1;
+                        const int pc = (q % C::PROWI) * 16 + row16;
+                        int iy = y0 - g.pad + pr, ix = x0 - g.pad + pc;
+                        bool ok = pc < TW + 2;
+                        if (g.pad_mode) { iy = p3_reflect(iy, g.H); ix = p3_reflect(ix, g.W); ok = ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W; }
+                        else ok = ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+                        if (ok) v = (unsigned)((((long)n * g.H + iy) * g.W + ix) * g.ldx * 2 + g.ci_off * 2 + chunk * 16);
+                    }
+                }
+                voff[ky][j] = v;
+            }
+        int is = 0;   // next K-step to stage
+        auto issue = [&]<int KY>(std::integral_constant<int, KY>) {
+            const bool live = is < NK;
+            const int hs = is / 3;                       // 32-channel slice index (KY == is % 3 by construction)
+            const int cc = hs >> 1, half = hs & 1;
+            const unsigned w_soff = (unsigned)((cc * 9 + KY * 3) * 128 + half * 64);
+            const unsigned x_soff = (unsigned)((cc * 64 + half * 32) * 2);
+            unsigned char *wdst = wring + (is % C::NSTW) * C::WST;
+            unsigned char *pdst = pbufs + (hs & 1) * C::PBUF;
+#pragma unroll
+            for (int j = 0; j < C::nl(KY); ++j) {
+                const int id = lw + NLW * j;             // wave-uniform
+                const unsigned v = live ? voff[KY][j] : P3_OOB;
+                if (id < C::NW) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (p3_lptr_t)(wdst + id * 1024), 16, v, w_soff, 0, 0);
+                } else if (id < C::NW + C::np(KY)) {
+                    const int q = id - C::NW;
+                    const int slot = KY == 0 ? q : (KY + 1) * C::PROWI + q;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (p3_lptr_t)(pdst + slot * 1024), 16, v, x_soff, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (p3_lptr_t)dummy, 16, P3_OOB, 0, 0, 0);
+                }
+            }
+            ++is;
+        };
+        // prologue: AHEAD steps (phases 0 .. AHEAD-1)
+        issue(std::integral_constant<int, 0>{});
+        if constexpr (C::AHEAD >= 2) issue(std::integral_constant<int, 1>{});
+        if constexpr (C::AHEAD >= 3) issue(std::integral_constant<int, 2>{});
+        for (int hs = 0; hs < g.kchunks * 2; ++hs) {
+            auto step = [&]<int KY>(std::integral_constant<int, KY>) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::out(KY)) : "memory");   // this step's operands have landed
+                __builtin_amdgcn_s_barrier();                                         // ... and the previous step is consumed
+                issue(std::integral_constant<int, (KY + C::AHEAD) % 3>{});
+            };
+            step(std::integral_constant<int, 0>{});
+            step(std::integral_constant<int, 1>{});
+            step(std::integral_constant<int, 2>{});
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        // =============================== multiplying waves ===============================
+        const int wm = wave / C::WN, wn = wave - wm * C::WN;
+        const int l15 = lane & 15, grp = lane >> 4;
+        unsigned aofs[MI], bofs[NI][3];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) aofs[mi] = (unsigned)((wm * 64 + mi * 16 + l15) * 64 + ((grp ^ ((l15 >> 2) & 3)) * 16));
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int p = wn * C::PXW + ni * 16, ty = p / TW, tx = p - ty * TW;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)   // entry (ty+ky)*PWP + tx + l15 + kx; PWP and tx are multiples of 16
+                bofs[ni][kx] = (unsigned)((ty * C::PWP + tx + l15 + kx) * 64 + ((grp ^ (((l15 + kx) >> 2) & 3)) * 16));
+        }
+        int ks = 0;
+        for (int hs = 0; hs < g.kchunks * 2; ++hs) {
+            const unsigned char *patch = pbufs + (hs & 1) * C::PBUF;
+            auto step = [&]<int KY>(std::integral_constant<int, KY>) {
+                __builtin_amdgcn_s_barrier();
+                const unsigned char *wst = wring + (ks % C::NSTW) * C::WST;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    frag a[MI], b[NI];
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const frag *>(wst + aofs[mi] + kx * TCO * 64);
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        b[ni] = *reinterpret_cast<const frag *>(patch + bofs[ni][kx] + KY * C::PWP * 64);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = Hf::mfma(a[mi], b[ni], acc[mi][ni]);
+                }
+                ++ks;
+            };
+            step(std::integral_constant<int, 0>{});
+            step(std::integral_constant<int, 1>{});
+            step(std::integral_constant<int, 2>{});
+        }
+    }
+
+    // ---------------- epilogue ----------------
+    __builtin_amdgcn_s_barrier();   // every wave is past its last LDS read / its last DMA has landed: smem is reusable
+    float *red = reinterpret_cast<float *>(smem);   // [WN][TCO][2]
+    if (!loader) {
+        const int wm = wave / C::WN, wn = wave - wm * C::WN;
+        const int l15 = lane & 15, grp = lane >> 4;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int cl = wm * 64 + mi * 16 + grp * 4;      // cout within the tile
+            const int co = ct * TCO + cl;
+            float bv[4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[r] = bias ? bias[co + r] : 0.f;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int p = wn * C::PXW + ni * 16 + l15, ty = p / TW, tx = p - ty * TW;
+                const int oy = y0 + ty, ox = x0 + tx;
+                const bool valid = oy < g.Ho && ox < g.Wo;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = acc[mi][ni][r] + bv[r];
+                    if (g.act) v[r] = v[r] > 0.f ? v[r] : (g.act == 1 ? 0.2f : 0.1f) * v[r];
+                    if (valid) { s1[r] += v[r]; s2[r] += v[r] * v[r]; }
+                }
+                if (valid) {
+                    uint2 pk;
+                    pk.x = (uint32_t)Hf::cvt(v[0]) | ((uint32_t)Hf::cvt(v[1]) << 16);
+                    pk.y = (uint32_t)Hf::cvt(v[2]) | ((uint32_t)Hf::cvt(v[3]) << 16);
+                    *reinterpret_cast<uint2 *>(Y + (((long)n * g.Ho + oy) * g.Wo + ox) * g.ldy + g.co_off + co) = pk;
+                }
+            }
+            if (stats_partial != nullptr) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s1[r] = row16_sum(s1[r]); s2[r] = row16_sum(s2[r]); }
+                if (l15 == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        red[(wn * TCO + cl + r) * 2 + 0] = s1[r];
+                        red[(wn * TCO + cl + r) * 2 + 1] = s2[r];
+                    }
+                }
+            }
+        }
+    }
+    if (stats_partial != nullptr) {
+        __builtin_amdgcn_s_barrier();
+        if (tid < TCO * 2) {   // tid < 256: the multiplying waves
+            const int cl = tid >> 1, which = tid & 1;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < C::WN; ++w) t += red[(w * TCO + cl) * 2 + which];
+            stats_partial[((long)(g.stats_row0 + pt) * 2 + which) * g.Cout + ct * TCO + cl] = t;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// host side (called from conv_mfma.hip)
+// ----------------------------------------------------------------------------------------
+static bool p3_enabled() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("IR2RGB_CONV3X3P"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
+
+// variant: 0 = not applicable, 1 = 2x64 px x 64 cout (8 loader waves), 2 = 2x128 px x 128 cout (4 loader waves)
+int conv3x3p_plan(const ir2rgb_conv_desc *d, P3Geom *g, int *npt_out) {
+    if (!p3_enabled() || d->transposed || d->kh != 3 || d->kw != 3 || d->stride_h != 1 || d->stride_w != 1) return 0;
+    if (d->pad_h != d->pad_w || d->pad_h < 0 || d->pad_h > 2 || d->out_f32) return 0;
+    if (d->Hout != d->Hin + 2 * d->pad_h - 2 || d->Wout != d->Win + 2 * d->pad_w - 2) return 0;
+    if ((d->Cin % 64) || d->Cin < 256 || (d->Cout % 64) || d->Hin < 4 || d->Win < 4 || d->N < 1) return 0;
+    if (d->dtype != IR2RGB_BF16 && d->dtype != IR2RGB_F16) return 0;
+    const int ldx = d->ldx > 0 ? d->ldx : d->Cin, ldy = d->ldy > 0 ? d->ldy : d->Cout;
+    if ((ldx & 7) || (d->ci_off & 7) || (ldy & 3) || (d->co_off & 3)) return 0;
+    const long xb = (long)d->N * d->Hin * d->Win * ldx * 2, wb = (long)d->Cout * d->Cin * 9 * 2;
+    if (xb >= (1L << 31) || wb >= (1L << 31)) return 0;
+    auto waste = [](int n, int t) { return (double)(((n + t - 1) / t) * t) / n; };
+    int variant = 0;
+    const double wr = waste(d->Hout, 2);
+    const long t128 = (long)d->N * ((d->Hout + 1) / 2) * ((d->Wout + 127) / 128) * (d->Cout / 128);
+    const long t64 = (long)d->N * ((d->Hout + 1) / 2) * ((d->Wout + 63) / 64) * (d->Cout / 64);
+    if ((d->Cout % 128) == 0 && wr * waste(d->Wout, 128) <= 1.13 && t128 >= 200) variant = 2;
+    else if (wr * waste(d->Wout, 64) <= 1.13 && t64 >= 200) variant = 1;
+    if (!variant) return 0;
+    const int tw = variant == 2 ? 128 : 64;
+    *g = P3Geom{};
+    g->N = d->N; g->H = d->Hin; g->W = d->Win; g->Ho = d->Hout; g->Wo = d->Wout; g->Cin = d->Cin; g->Cout = d->Cout;
+    g->pad = d->pad_h; g->pad_mode = d->pad_mode; g->act = d->act;
+    g->ldx = ldx; g->ci_off = d->ci_off; g->ldy = ldy; g->co_off = d->co_off;
+    g->stats_row0 = 0; g->nty = (d->Hout + 1) / 2; g->ntx = (d->Wout + tw - 1) / tw;
+    g->kchunks = d->Cin / 64;
+    g->x_bytes = (unsigned)xb; g->w_bytes = (unsigned)wb;
+    g->cout_major = wb > (long)d->N * d->Hin * d->Win * d->Cin * 2 ? 1 : 0;
+    if (d->pad_mode && (d->pad_h >= d->Hin || d->pad_w >= d->Win)) return 0;
+    *npt_out = d->N * g->nty * g->ntx;
+    return variant;
+}
+
+int conv3x3p_launch(int variant, const P3Geom &g, int dtype, const void *x, const void *wp, const float *bias, void *y,
+                    float *stats, hipStream_t s) {
+    const uint16_t *X = (const uint16_t *)x, *W = (const uint16_t *)wp;
+    uint16_t *Yp = (uint16_t *)y;
+    const int npt = g.N * g.nty * g.ntx;
+    if (variant == 2) {
+        const unsigned grid = (unsigned)(npt * (g.Cout / 128));
+        if (dtype == IR2RGB_BF16) conv3x3_patch_kernel<IR2RGB_BF16, 128, 128, 8, 4><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+        else conv3x3_patch_kernel<IR2RGB_F16, 128, 128, 8, 4><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+    } else {
+        const unsigned grid = (unsigned)(npt * (g.Cout / 64));
+        if (dtype == IR2RGB_BF16) conv3x3_patch_kernel<IR2RGB_BF16, 64, 64, 4, 8><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+        else conv3x3_patch_kernel<IR2RGB_F16, 64, 64, 4, 8><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+    }
+    return ir2rgb_launch_status();
+}

@@ -750,7 +750,25 @@ extern "C" long ir2rgb_conv2d_packed_weight_elems(const ir2rgb_conv_desc *d) {
     return e;
 }
 
+// conv3x3_patch.hip: the patch-staged kernel for 3x3 / stride-1 layers with >= 256 input channels
+struct P3Geom {
+    int N, H, W, Ho, Wo, Cin, Cout;
+    int pad, pad_mode, act;
+    int ldx, ci_off, ldy, co_off;
+    int stats_row0, nty, ntx;
+    int cout_major, kchunks;
+    unsigned x_bytes, w_bytes;
+};
+int conv3x3p_plan(const ir2rgb_conv_desc *d, P3Geom *g, int *npt_out);
+int conv3x3p_launch(int variant, const P3Geom &g, int dtype, const void *x, const void *wp, const float *bias, void *y,
+                    float *stats, hipStream_t s);
+
 extern "C" int ir2rgb_conv2d_stats_rows(const ir2rgb_conv_desc *d) {
+    {
+        P3Geom g3;
+        int npt3 = 0;
+        if (d && conv3x3p_plan(d, &g3, &npt3)) return npt3;
+    }
     ClassPlan plans[4];
     int n = make_plan(d, plans);
     if (n < 0) return n;
@@ -848,6 +866,12 @@ extern "C" int ir2rgb_conv2d_fwd(const ir2rgb_conv_desc *d, const void *x, const
     int n = make_plan(d, plans);
     if (n < 0) return n;
     if ((((uintptr_t)x | (uintptr_t)wpacked | (uintptr_t)y) & 15) != 0) return IR2RGB_EALIGN;
+    {
+        P3Geom g3;
+        int npt3 = 0;
+        const int variant = conv3x3p_plan(d, &g3, &npt3);
+        if (variant) return conv3x3p_launch(variant, g3, d->dtype, x, wpacked, bias, y, stats_partial, as_stream(stream));
+    }
     if (n > 1 && merge_classes()) {
         // one launch for all classes: same pixel-tile size for all of them (plans were made with it)
         ConvClasses cs;

@@ -57,17 +57,19 @@ class Workspace:
     """Per-(sub-network, input shape) pool of NHWC buffers, allocated and zero-filled once.  Buffers are
     handed out in call order; pad channels are never written, so they stay zero across calls, and every
     real channel is overwritten by its producer on each forward."""
-    _pools = {}
     _current = None
 
     def __init__(self):
         self.bufs, self.cursor = [], 0
 
     @classmethod
-    def activate(cls, key):
-        ws = cls._pools.get(key)
+    def activate(cls, net, key):
+        """The pool of (net, key), created on first use.  Pools live ON the sub-network module (not in a
+        table keyed by id(net): ids are recycled once a network is garbage collected)."""
+        pools = net.__dict__.setdefault("_ir2rgb_workspaces", {})
+        ws = pools.get(key)
         if ws is None:
-            ws = cls._pools[key] = Workspace()
+            ws = pools[key] = Workspace()
         ws.cursor = 0
         cls._current = ws
         return ws
@@ -204,7 +206,7 @@ def _dense(n, ch, h, w, dtype, device):
 
 def flownetc(net, x, dtype):
     """x [N,6,H,W] fp32 (two normalised images) -> flow2 [N,2,H/4,W/4] fp32 (reference FlowNetC.py:75-126)."""
-    Workspace.activate((id(net), tuple(x.shape), dtype, x.device))
+    Workspace.activate(net, (tuple(x.shape), dtype, x.device))
     n, _, H, W = x.shape
     dev = x.device
     dec = _Decoder(n, H // 64, W // 64, dtype, dev)
@@ -228,7 +230,7 @@ def flownetc(net, x, dtype):
 
 def flownets(net, x, dtype):
     """x [N,12,H,W] fp32 -> flow2 (reference FlowNetS.py:57-93)."""
-    Workspace.activate((id(net), tuple(x.shape), dtype, x.device))
+    Workspace.activate(net, (tuple(x.shape), dtype, x.device))
     n, _, H, W = x.shape
     dev = x.device
     dec = _Decoder(n, H // 64, W // 64, dtype, dev)
@@ -244,7 +246,7 @@ def flownets(net, x, dtype):
 
 def flownetsd(net, x, dtype):
     """x [N,6,H,W] fp32 -> flow2 (reference FlowNetSD.py:66-105)."""
-    Workspace.activate((id(net), tuple(x.shape), dtype, x.device))
+    Workspace.activate(net, (tuple(x.shape), dtype, x.device))
     n, _, H, W = x.shape
     dev = x.device
     dec = _Decoder(n, H // 64, W // 64, dtype, dev)
@@ -262,7 +264,7 @@ def flownetsd(net, x, dtype):
 
 def flownetfusion(net, x, dtype):
     """x [N,11,H,W] fp32 -> flow0 [N,2,H,W] (reference FlowNetFusion.py:47-66)."""
-    Workspace.activate((id(net), tuple(x.shape), dtype, x.device))
+    Workspace.activate(net, (tuple(x.shape), dtype, x.device))
     n, _, H, W = x.shape
     dev = x.device
     cat0 = new_buf(n, 128, H, W, dtype, dev)            # [conv0 64 | deconv0 16 | flow1_up 2 | pad]

@@ -97,9 +97,12 @@ def frozen(module):
 class FlowNet(torch.nn.Module):
     """Frozen FlowNet2 + confidence mask (models/flownet.py)."""
 
-    def __init__(self, conv_dtype=torch.bfloat16, seed=1):
+    def __init__(self, conv_dtype=torch.bfloat16, seed=1, use_graph=None):
         super().__init__()
         from .flownet2_pytorch.models import FlowNet2
+        import os
+        self.use_graph = (os.environ.get("IR2RGB_FLOWNET_GRAPH", "1") != "0") if use_graph is None else bool(use_graph)
+        self._graphs = {}   # shape key -> call count | (graph, in1, in2, (flow, conf)) | False (capture failed)
         rng = torch.random.get_rng_state()
         torch.manual_seed(seed)  # no checkpoint offline: the reference's own init (models.py:68-77)
         self.flowNet = FlowNet2(conv_dtype=conv_dtype)
@@ -117,6 +120,38 @@ class FlowNet(torch.nn.Module):
         return self.compute_flow_and_conf(input_A, input_B)
 
     def compute_flow_and_conf(self, im1, im2):
+        """FlowNet2 is frozen, runs without autograd and with fixed shapes: ~330 small launches per call.
+        After two eager calls at a shape the whole call (convolutions, operators, interpolations, the
+        confidence mask) is captured into a HIP graph and replayed -- one launch, no host work between
+        the kernels.  Any failure to capture falls back to the eager path for that shape (logged once)."""
+        key = (tuple(im1.shape), im1.dtype, str(im1.device))
+        ent = self._graphs.get(key)
+        if not self.use_graph or not im1.is_cuda or ent is False:
+            return self._flow_and_conf_eager(im1, im2)
+        if ent is None or isinstance(ent, int):
+            n = (ent or 0) + 1
+            self._graphs[key] = n
+            if n <= 2:
+                return self._flow_and_conf_eager(im1, im2)
+            try:
+                a, b = im1.clone(), im2.clone()
+                torch.cuda.synchronize(im1.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    out = self._flow_and_conf_eager(a, b)
+                ent = self._graphs[key] = (g, a, b, out)
+            except Exception as e:  # noqa: BLE001  capture is an optimisation, never a requirement
+                self._graphs[key] = False
+                print(f"[ir2rgb_amd] FlowNet2 graph capture failed at {key[0]} ({type(e).__name__}: {e}); staying eager",
+                      flush=True)
+                return self._flow_and_conf_eager(im1, im2)
+        g, a, b, (flow, conf) = ent
+        a.copy_(im1)
+        b.copy_(im2)
+        g.replay()
+        return flow.clone(), conf.clone()   # the graph owns its outputs: the next replay overwrites them
+
+    def _flow_and_conf_eager(self, im1, im2):
         assert im1.size(1) == 3 and im1.shape == im2.shape
         old_h, old_w = im1.shape[2:]
         new_h, new_w = old_h // 64 * 64, old_w // 64 * 64

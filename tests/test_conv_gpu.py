@@ -67,6 +67,11 @@ CASES = [
     (1, 64, 128, 256, 128, 3, 1, 1, 1, False, 0),    # 32768 pixels -> TP=256 path
     (1, 64, 12, 20, 130, 1, 1, 0, 0, False, 0),      # 1x1 (runtime tap path), ragged Cout
     (1, 64, 40, 24, 128, 7, 1, 3, 1, False, 0),      # 7x7 reflect (runtime tap path, 49 taps)
+    # patch-staged 3x3 kernel (conv3x3_patch.hip): Cin >= 256, >= 200 tiles
+    (1, 256, 101, 250, 256, 3, 1, 1, 1, False, 0),   # 2x128 px x 128 cout tiles, reflect, ragged rows / columns
+    (1, 256, 64, 126, 1024, 3, 1, 2, 0, False, 0),   # data-gradient geometry: zero pad 2, output 66x128
+    (1, 320, 67, 128, 192, 3, 1, 1, 0, False, 0),    # 2x64 px x 64 cout tiles (Cout % 128 != 0), zero pad, 5 K chunks
+    (2, 256, 34, 64, 320, 3, 1, 1, 1, False, 0),     # 2x64 tiles, batch 2, reflect
 ]
 
 
