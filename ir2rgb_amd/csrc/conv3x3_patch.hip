@@ -359,12 +359,18 @@ static bool p3_enabled() {
     return v != 0;
 }
 
+static int p3_min_cin() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("IR2RGB_CONV3X3P_MIN_CIN"); v = e ? atoi(e) : 256; }
+    return v;
+}
+
 // variant: 0 = not applicable, 1 = 2x64 px x 64 cout (8 loader waves), 2 = 2x128 px x 128 cout (4 loader waves)
 int conv3x3p_plan(const ir2rgb_conv_desc *d, P3Geom *g, int *npt_out) {
     if (!p3_enabled() || d->transposed || d->kh != 3 || d->kw != 3 || d->stride_h != 1 || d->stride_w != 1) return 0;
     if (d->pad_h != d->pad_w || d->pad_h < 0 || d->pad_h > 2 || d->out_f32) return 0;
     if (d->Hout != d->Hin + 2 * d->pad_h - 2 || d->Wout != d->Win + 2 * d->pad_w - 2) return 0;
-    if ((d->Cin % 64) || d->Cin < 256 || (d->Cout % 64) || d->Hin < 4 || d->Win < 4 || d->N < 1) return 0;
+    if ((d->Cin % 64) || d->Cin < p3_min_cin() || (d->Cout % 64) || d->Hin < 4 || d->Win < 4 || d->N < 1) return 0;
     if (d->dtype != IR2RGB_BF16 && d->dtype != IR2RGB_F16) return 0;
     const int ldx = d->ldx > 0 ? d->ldx : d->Cin, ldy = d->ldy > 0 ? d->ldy : d->Cout;
     if ((ldx & 7) || (d->ci_off & 7) || (ldy & 3) || (d->co_off & 3)) return 0;
