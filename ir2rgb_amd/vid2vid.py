@@ -178,13 +178,14 @@ class FlatGrads:
 
     def __init__(self, params, chunk_elems=32 * 1024 * 1024):
         self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
+        pad4 = lambda k: (k + 3) & ~3  # noqa: E731  every view starts on a 16-byte boundary (vector path of adam_kernel)
+        n = sum(pad4(p.numel()) for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         self.views, off = [], 0
         for p in self.params:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
+            off += pad4(p.numel())
         self.chunk = chunk_elems
         self.handles = []
 

@@ -44,7 +44,8 @@ def _worker(rank, world, port, outdir):
         assert all(lo <= p.grad.data_ptr() < hi for p in fg.params)  # gathered: views of the flat buffer
         fg.wait()
         opt.step()
-    torch.save((rank, fg.flat.clone(), torch.cat([p.detach().reshape(-1) for p in m.parameters()])),
+    # the flat buffer pads every view to a 16-byte boundary: compare the views, not the raw buffer
+    torch.save((rank, torch.cat([v.reshape(-1) for v in fg.views]).clone(), torch.cat([p.detach().reshape(-1) for p in m.parameters()])),
                os.path.join(outdir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()

@@ -1,0 +1,20 @@
+"""torch.profiler view of the north-star generator forward (which aten ops launch what)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torch.profiler import profile, ProfilerActivity
+from ir2rgb_amd import networks as N
+dev = torch.device("cuda:0")
+opt = dict(gen_blocks=9, n_blocks_local=3, fg=False, no_flow=False, n_local_enhancers=1, feat_num=3)
+torch.manual_seed(0)
+g = N.build_generator_module(9, 3, 6, 128, "composite", 3, "batch", 0, **opt).to(dev).train()
+x, p = torch.tanh(torch.randn(1, 9, 512, 1024, device=dev)), torch.tanh(torch.randn(1, 6, 512, 1024, device=dev))
+with torch.no_grad():
+    for _ in range(3):
+        g(x, p, None, None, None, None, False)
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+        for _ in range(3):
+            g(x, p, None, None, None, None, False)
+        torch.cuda.synchronize()
+print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=30, max_name_column_width=60))
