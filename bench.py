@@ -106,7 +106,7 @@ def main():
     def shape_totals(prof):
         out = {}
         for key, rec in prof.get("shapes", {}).items():
-            out[key] = (sum(a.elapsed_time(b) for a, b in rec["events"]) * 1e-3, len(rec["events"]), rec["flops"])
+            out[key] = (sum(a.elapsed_time(b) for a, b in rec["events"]) * 1e-3, len(rec["events"]), rec["flops"], rec["kernel"])
         return out
 
     i = 0
@@ -151,12 +151,12 @@ def main():
             return None
 
     # ---- roofline of the dominant kernel: HIP events around each of its launches inside the timed region
-    tot, n_launch, flops = prof[dominant]
+    tot, n_launch, flops, kernel_name = prof[dominant]
     avg = tot / n_launch
     achieved = flops / avg / 1e12
     roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic_of(dominant),
-                "kernel": "conv_igemm_kernel (MFMA implicit GEMM)",
+                "kernel": kernel_name + " (MFMA implicit GEMM)",
                 "shape": dict(zip(("Cin", "Hin", "Win", "Cout", "kh", "kw", "stride", "reflect", "transposed"), dominant)),
                 "launches": n_launch, "avg_us": round(avg * 1e6, 1), "flops_per_launch": flops,
                 "note": "launches that overlap side-stream weight gradients are not bracketed (see DESIGN.md)"}

@@ -145,6 +145,10 @@ int ir2rgb_conv2d_pack_weight_adjoint(const ir2rgb_conv_desc *d, const float *w,
 int ir2rgb_conv2d_fwd(const ir2rgb_conv_desc *d, const void *x, const void *wpacked, const float *bias, void *y,
                       float *stats_partial, void *stream);
 
+/* Name of the device kernel ir2rgb_conv2d_fwd launches for `d` ("conv3x3_patch_kernel",
+ * "conv_igemm_kernel", "conv_igemm_classes_kernel"; "" for an invalid descriptor): for profiles. */
+const char *ir2rgb_conv2d_kernel_name(const ir2rgb_conv_desc *d);
+
 /* Training-mode BatchNorm2d statistics (reference norm_layer = nn.BatchNorm2d, networks.py:41-48).
  * Reduces the [rows][2][C] partial sums written by ir2rgb_conv2d_fwd over `count` pixels into
  * scale = gamma*invstd and shift = beta - mean*scale, and updates running_mean / running_var

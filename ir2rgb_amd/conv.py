@@ -105,7 +105,11 @@ def _prof_end(tok, desc):
     prof, key, e0 = tok
     e1 = torch.cuda.Event(enable_timing=True)
     e1.record()
-    prof.setdefault("shapes", {}).setdefault(key, {"flops": _flops(desc), "events": []})["events"].append((e0, e1))
+    rec = prof.setdefault("shapes", {}).get(key)
+    if rec is None:
+        name = _lib.lib().ir2rgb_conv2d_kernel_name(ctypes.byref(desc)).decode()
+        rec = prof["shapes"][key] = {"flops": _flops(desc), "events": [], "kernel": name}
+    rec["events"].append((e0, e1))
 
 
 def _flops(desc):

@@ -763,6 +763,17 @@ int conv3x3p_plan(const ir2rgb_conv_desc *d, P3Geom *g, int *npt_out);
 int conv3x3p_launch(int variant, const P3Geom &g, int dtype, const void *x, const void *wp, const float *bias, void *y,
                     float *stats, hipStream_t s);
 
+extern "C" const char *ir2rgb_conv2d_kernel_name(const ir2rgb_conv_desc *d) {
+    if (!d) return "";
+    P3Geom g3;
+    int npt3 = 0;
+    if (conv3x3p_plan(d, &g3, &npt3)) return "conv3x3_patch_kernel";
+    ClassPlan plans[4];
+    const int n = make_plan(d, plans);
+    if (n < 0) return "";
+    return (n > 1 && merge_classes()) ? "conv_igemm_classes_kernel" : "conv_igemm_kernel";
+}
+
 extern "C" int ir2rgb_conv2d_stats_rows(const ir2rgb_conv_desc *d) {
     {
         P3Geom g3;
