@@ -90,8 +90,8 @@ def _prof_key(desc):
 
 def _prof_begin(desc):
     prof = PROFILE
-    if prof is None or SIDE_BUSY:
-        return None
+    if prof is None or SIDE_BUSY or torch.cuda.is_current_stream_capturing():
+        return None   # (events recorded while a HIP graph is being captured are graph nodes, not timers)
     key = _prof_key(desc)
     only = prof.get("only")
     if only is not None and only != key:
