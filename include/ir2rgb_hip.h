@@ -114,7 +114,12 @@ typedef struct ir2rgb_conv_desc {
     int N, Hin, Win, Cin;   /* input  [N,Hin,Win,Cin]  NHWC, Cin % 64 == 0 */
     int Hout, Wout, Cout;   /* output [N,Hout,Wout,Cout] NHWC              */
     int kh, kw, stride_h, stride_w, pad_h, pad_w;
-    int pad_mode;           /* 0: zero padding, 1: reflection padding (nn.ReflectionPad2d) */
+    int pad_mode;           /* 0: zero padding, 1: reflection padding (nn.ReflectionPad2d), 2: ADJOINT of reflection
+                             * padding: the call is the data gradient of a reflection-padded 3x3 / stride-1 / pad-1
+                             * convolution (x = its output gradient, wpacked = its adjoint-packed weights, y = the
+                             * input gradient, same H x W); only where ir2rgb_conv2d_kernel_name() says
+                             * "conv3x3_patch_kernel", IR2RGB_ENOSUP otherwise (then: zero padding 2 on the padded
+                             * grid + ir2rgb_fold_reflect) */
     int transposed;         /* 0: Conv2d, 1: ConvTranspose2d (stride 1 or 2 per axis; Hout/Wout carry output_padding) */
     int dtype;              /* IR2RGB_BF16 or IR2RGB_F16: activations and packed weights */
     int act;                /* fused after bias: 0 none, 1 LeakyReLU(0.2), 2 LeakyReLU(0.1) */

@@ -113,6 +113,15 @@ def conv_dgrad(gy, conv, spec, x_shape, weight_fn=None, tag="dgrad"):
         return dx
     if sh == 1 and sw == 1:
         if spec["pad_mode"] == C.PAD_REFLECT:
+            if (kh, kw, ph, pw) == (3, 3, 1, 1):
+                # the patch-staged kernel evaluates the adjoint of the reflection in place (border terms):
+                # no padded 2-pixel-larger output grid, no fold pass
+                dadj = C.make_desc(tuple(gy.shape), cin, 3, 1, 1, C.PAD_REFLECT_ADJ, dt)
+                if C.kernel_name(dadj) == "conv3x3_patch_kernel":
+                    dpack = C.make_desc(tuple(gy.shape), cin, 3, 1, 1, C.PAD_ZERO, dt)
+                    wp = L.packed_weight(conv, dpack, weight_fn, tag=tag, adjoint=True)
+                    dx, _ = C.conv2d_fwd(dadj, gy, wp)
+                    return dx
             desc = C.make_desc(tuple(gy.shape), cin, (kh, kw), 1, (kh - 1, kw - 1), C.PAD_ZERO, dt)
             wp = L.packed_weight(conv, desc, weight_fn, tag=tag, adjoint=True)
             dxpad, _ = C.conv2d_fwd(desc, gy, wp)

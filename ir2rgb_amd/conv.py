@@ -14,6 +14,7 @@ from ._lib import ConvDesc
 BF16, F16 = 1, 2
 _TORCH2DT = {torch.bfloat16: BF16, torch.float16: F16}
 PAD_ZERO, PAD_REFLECT = 0, 1
+PAD_REFLECT_ADJ = 2   # the launch is the data gradient of a reflection-padded 3x3 conv (see include/ir2rgb_hip.h)
 ACT_NONE, ACT_LEAKY02 = 0, 1
 
 
@@ -40,6 +41,18 @@ def make_desc(x_shape, cout, k, stride, pad, pad_mode, dtype, transposed=False, 
     wo = out_size(w, kw, sw, pw, transposed, output_padding)
     return ConvDesc(n, h, w, cin, ho, wo, cout, kh, kw, sh, sw, ph, pw, pad_mode, int(transposed), _TORCH2DT[dtype],
                     act, int(out_f32), ldx, ci_off, ldy, co_off)
+
+
+_KERNEL_NAMES = {}
+
+
+def kernel_name(desc):
+    """Device kernel ir2rgb_conv2d_fwd would launch for ``desc`` ('' if it cannot run it); cached per descriptor."""
+    key = bytes(desc)
+    name = _KERNEL_NAMES.get(key)
+    if name is None:
+        name = _KERNEL_NAMES[key] = _lib.lib().ir2rgb_conv2d_kernel_name(ctypes.byref(desc)).decode()
+    return name
 
 
 def is_nhwc(t):

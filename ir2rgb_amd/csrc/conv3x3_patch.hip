@@ -64,7 +64,7 @@ __device__ __forceinline__ int p3_reflect(int v, int n) {
     return v >= n ? 2 * n - 2 - v : v;
 }
 
-template <int TW, int TCO, int NCW, int NLW> struct P3Cfg {
+template <int TW, int TCO, int NCW, int NLW, int ADJ> struct P3Cfg {
     static constexpr int TR = 2, NPX = TR * TW;
     static constexpr int PWP = ((TW + 2 + 15) / 16) * 16;   // patch row pitch in entries (80 | 144)
     static constexpr int PROWI = PWP / 16;                   // DMA instructions per patch row
@@ -75,7 +75,9 @@ template <int TW, int TCO, int NCW, int NLW> struct P3Cfg {
     static constexpr int AHEAD = NSTW - 1;
     static constexpr int WM = TCO / 64, WN = NCW / WM, PXW = NPX / WN, NI = PXW / 16;
     static constexpr int LDS = NSTW * WST + 2 * PBUF + 1024;
-    static constexpr int np(int ky) { return ky == 0 ? 2 * PROWI : PROWI; }
+    // patch rows staged with the step of phase ky: rows {0,1} | {2} | {3}; reflect-adjoint mode needs every row from
+    // the first step on (its border terms read row 2 at ky = 0), so it stages all four with ky = 0
+    static constexpr int np(int ky) { return ADJ ? (ky == 0 ? 4 * PROWI : 0) : (ky == 0 ? 2 * PROWI : PROWI); }
     static constexpr int nl(int ky) { return (NW + np(ky) + NLW - 1) / NLW; }     // DMA instructions per loader wave
     static constexpr int NLMAX = nl(0);
     // DMA instructions a loader wave may leave in flight while step (phase ky) is consumed: the steps staged after it
@@ -86,11 +88,12 @@ template <int TW, int TCO, int NCW, int NLW> struct P3Cfg {
     }
 };
 
-template <int DT, int TW, int TCO, int NCW, int NLW, int PIPE>
+template <int DT, int TW, int TCO, int NCW, int NLW, int PIPE, int ADJ>
 __global__ void __launch_bounds__((NCW + NLW) * 64, 1)
 conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Wp, const float *__restrict__ bias,
                      uint16_t *__restrict__ Y, float *__restrict__ stats_partial, const P3Geom g) {
-    typedef P3Cfg<TW, TCO, NCW, NLW> C;
+    typedef P3Cfg<TW, TCO, NCW, NLW, ADJ> C;
+    static_assert(!(ADJ && PIPE), "reflect-adjoint terms read the patch after the tap they belong to: plain loop only");
     typedef P3Half<DT> Hf;
     typedef typename Hf::frag frag;
     constexpr int NI = C::NI, MI = 4;
@@ -148,11 +151,11 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
                         v = (unsigned)((((long)co * g.kchunks) * 9 + kx) * 128 + chunk * 16);
                     } else if (id < C::NW + C::np(ky)) {
                         const int q = id - C::NW;
-                        const int pr = ky == 0 ? q / C::PROWI : ky + 1;
+                        const int pr = ky == 0 ? q / C::PROWI : ky + 1;   // (ADJ: ky == 0 covers rows 0..3)
                         const int pc = (q % C::PROWI) * 16 + row16;
                         int iy = y0 - g.pad + pr, ix = x0 - g.pad + pc;
                         bool ok = pc < TW + 2;
-                        if (g.pad_mode) { iy = p3_reflect(iy, g.H); ix = p3_reflect(ix, g.W); ok = ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W; }
+                        if (g.pad_mode == 1) { iy = p3_reflect(iy, g.H); ix = p3_reflect(ix, g.W); ok = ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W; }
                         else ok = ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
                         if (ok) v = (unsigned)((((long)n * g.H + iy) * g.W + ix) * g.ldx * 2 + g.ci_off * 2 + chunk * 16);
                     }
@@ -233,6 +236,37 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = Hf::mfma(fa[buf][mi], fb[buf][ni], acc[mi][ni]);
         };
+        // Reflect-adjoint mode (pad_mode 2): this launch is the data gradient of a reflection-padded 3x3 convolution,
+        //   dx(q) = sum over padded positions u that reflect onto q of F(u),  F = full correlation of gy with the
+        //   flipped kernel (zero outside).  Besides u = q, row 1 also receives F(-1, .), row H-2 F(H, .), column 1
+        //   F(., -1), column W-2 F(., W), and the four pixels next to the corners the corner values.  Each of these is
+        //   a tap of the same weights applied to a patch entry of this tile at another offset:
+        //     F(-1, x)  = sum_sx Wf(+1, sx) gy(0, x+sx)    -> pixel row ty = 1 of a top tile, weights ky = 2, entries of ky = 0
+        //     F(H, x)   = sum_sx Wf(-1, sx) gy(H-1, x+sx)  -> pixel row ty = 0 of a bottom tile, weights ky = 0, entries of ky = 2
+        //     F(y, -1)  = sum_sy Wf(sy, +1) gy(y+sy, 0)    -> pixel tx = 1, weights kx = 2, the entry of kx = 0
+        //     F(y, W)   = sum_sy Wf(sy, -1) gy(y+sy, W-1)  -> pixel tx = TW-2, weights kx = 0, the entry of kx = 2
+        //   so the padded 34 x 66 output grid and the fold pass disappear.  (H even, W % TW == 0: whole tiles.)
+        const bool top = y0 == 0, bot = y0 == g.H - 2, left = x0 == 0, right = x0 + TW == g.W;
+        auto border_terms = [&]<int KY>(const unsigned char *patch, std::integral_constant<int, KY>, int kx) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int p = wn * C::PXW + ni * 16, ty = p / TW, tx = p - ty * TW;   // wave-uniform
+                auto term = [&](int kyoff, int kxb, int only_lane) {
+                    frag b = *reinterpret_cast<const frag *>(patch + (bofs[ni] ^ (kxb == 0 ? 0u : (kxb == 1 ? flip1 : flip2))) + kxb * 64 + kyoff);
+                    if (only_lane >= 0 && l15 != only_lane) b = frag{};
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = Hf::mfma(fa[0][mi], b, acc[mi][ni]);
+                };
+                if (KY == 2 && top && ty == 1) term(0, kx, -1);
+                if (KY == 0 && bot && ty == 0) term(2 * C::PWP * 64, kx, -1);
+                if (kx == 2 && left && tx == 0) term(KY * C::PWP * 64, 0, 1);
+                if (kx == 0 && right && tx == TW - 16) term(KY * C::PWP * 64, 2, 14);
+                if (KY == 2 && kx == 2 && top && left && ty == 1 && tx == 0) term(0, 0, 1);
+                if (KY == 2 && kx == 0 && top && right && ty == 1 && tx == TW - 16) term(0, 2, 14);
+                if (KY == 0 && kx == 2 && bot && left && ty == 0 && tx == 0) term(2 * C::PWP * 64, 0, 1);
+                if (KY == 0 && kx == 0 && bot && right && ty == 0 && tx == TW - 16) term(2 * C::PWP * 64, 2, 14);
+            }
+        };
         if constexpr (PIPE) {
             int ks = 0;
             __builtin_amdgcn_s_barrier();                       // step 0 has landed
@@ -283,6 +317,7 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
                     for (int kx = 0; kx < 3; ++kx) {
                         fetch(0, wst, patch, KY * C::PWP * 64, kx);
                         mma(0);
+                        if constexpr (ADJ) border_terms(patch, std::integral_constant<int, KY>{}, kx);
                     }
                     ++ks;
                 };
@@ -359,6 +394,12 @@ static bool p3_enabled() {
     return v != 0;
 }
 
+static long p3_min_tiles() {   // fewer tiles than this leave too much of the chip idle: the general kernel runs instead
+    static long v = -1;
+    if (v < 0) { const char *e = getenv("IR2RGB_CONV3X3P_MIN_TILES"); v = e ? atol(e) : 200; }
+    return v;
+}
+
 static int p3_min_cin() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("IR2RGB_CONV3X3P_MIN_CIN"); v = e ? atoi(e) : 256; }
@@ -369,6 +410,9 @@ static int p3_min_cin() {
 int conv3x3p_plan(const ir2rgb_conv_desc *d, P3Geom *g, int *npt_out) {
     if (!p3_enabled() || d->transposed || d->kh != 3 || d->kw != 3 || d->stride_h != 1 || d->stride_w != 1) return 0;
     if (d->pad_h != d->pad_w || d->pad_h < 0 || d->pad_h > 2 || d->out_f32) return 0;
+    if (d->pad_mode < 0 || d->pad_mode > 2) return 0;
+    const bool adj = d->pad_mode == 2;   // data gradient of a reflection-padded convolution (see border_terms)
+    if (adj && (d->pad_h != 1 || (d->Hin & 1) || (d->Win % 64))) return 0;
     if (d->Hout != d->Hin + 2 * d->pad_h - 2 || d->Wout != d->Win + 2 * d->pad_w - 2) return 0;
     if ((d->Cin % 64) || d->Cin < p3_min_cin() || (d->Cout % 64) || d->Hin < 4 || d->Win < 4 || d->N < 1) return 0;
     if (d->dtype != IR2RGB_BF16 && d->dtype != IR2RGB_F16) return 0;
@@ -381,8 +425,9 @@ int conv3x3p_plan(const ir2rgb_conv_desc *d, P3Geom *g, int *npt_out) {
     const double wr = waste(d->Hout, 2);
     const long t128 = (long)d->N * ((d->Hout + 1) / 2) * ((d->Wout + 127) / 128) * (d->Cout / 128);
     const long t64 = (long)d->N * ((d->Hout + 1) / 2) * ((d->Wout + 63) / 64) * (d->Cout / 64);
-    if ((d->Cout % 128) == 0 && wr * waste(d->Wout, 128) <= 1.13 && t128 >= 200) variant = 2;
-    else if (wr * waste(d->Wout, 64) <= 1.13 && t64 >= 200) variant = 1;
+    const long tmin = p3_min_tiles();
+    if ((d->Cout % 128) == 0 && wr * waste(d->Wout, 128) <= 1.13 && t128 >= tmin && (!adj || d->Win % 128 == 0)) variant = 2;
+    else if (wr * waste(d->Wout, 64) <= 1.13 && t64 >= tmin) variant = 1;
     if (!variant) return 0;
     const int tw = variant == 2 ? 128 : 64;
     *g = P3Geom{};
@@ -393,7 +438,7 @@ int conv3x3p_plan(const ir2rgb_conv_desc *d, P3Geom *g, int *npt_out) {
     g->kchunks = d->Cin / 64;
     g->x_bytes = (unsigned)xb; g->w_bytes = (unsigned)wb;
     g->cout_major = wb > (long)d->N * d->Hin * d->Win * d->Cin * 2 ? 1 : 0;
-    if (d->pad_mode && (d->pad_h >= d->Hin || d->pad_w >= d->Win)) return 0;
+    if (d->pad_mode == 1 && (d->pad_h >= d->Hin || d->pad_w >= d->Win)) return 0;
     *npt_out = d->N * g->nty * g->ntx;
     return variant;
 }
@@ -403,14 +448,25 @@ int conv3x3p_launch(int variant, const P3Geom &g, int dtype, const void *x, cons
     const uint16_t *X = (const uint16_t *)x, *W = (const uint16_t *)wp;
     uint16_t *Yp = (uint16_t *)y;
     const int npt = g.N * g.nty * g.ntx;
+    const bool adj = g.pad_mode == 2;
     if (variant == 2) {
         const unsigned grid = (unsigned)(npt * (g.Cout / 128));
-        if (dtype == IR2RGB_BF16) conv3x3_patch_kernel<IR2RGB_BF16, 128, 128, 8, 4, 0><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
-        else conv3x3_patch_kernel<IR2RGB_F16, 128, 128, 8, 4, 0><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+        if (adj) {
+            if (dtype == IR2RGB_BF16) conv3x3_patch_kernel<IR2RGB_BF16, 128, 128, 8, 4, 0, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+            else conv3x3_patch_kernel<IR2RGB_F16, 128, 128, 8, 4, 0, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+        } else {
+            if (dtype == IR2RGB_BF16) conv3x3_patch_kernel<IR2RGB_BF16, 128, 128, 8, 4, 0, 0><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+            else conv3x3_patch_kernel<IR2RGB_F16, 128, 128, 8, 4, 0, 0><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+        }
     } else {
         const unsigned grid = (unsigned)(npt * (g.Cout / 64));
-        if (dtype == IR2RGB_BF16) conv3x3_patch_kernel<IR2RGB_BF16, 64, 64, 4, 8, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
-        else conv3x3_patch_kernel<IR2RGB_F16, 64, 64, 4, 8, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+        if (adj) {
+            if (dtype == IR2RGB_BF16) conv3x3_patch_kernel<IR2RGB_BF16, 64, 64, 4, 8, 0, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+            else conv3x3_patch_kernel<IR2RGB_F16, 64, 64, 4, 8, 0, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+        } else {
+            if (dtype == IR2RGB_BF16) conv3x3_patch_kernel<IR2RGB_BF16, 64, 64, 4, 8, 1, 0><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+            else conv3x3_patch_kernel<IR2RGB_F16, 64, 64, 4, 8, 1, 0><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+        }
     }
     return ir2rgb_launch_status();
 }

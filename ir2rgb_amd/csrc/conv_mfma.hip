@@ -630,6 +630,7 @@ static int make_plan(const ir2rgb_conv_desc *d, ClassPlan plans[4]) {
         d->kh * d->kw > IR2RGB_MAX_TAPS || d->stride_h < 1 || d->stride_w < 1 || d->pad_h < 0 || d->pad_w < 0)
         return IR2RGB_EINVAL;
     if (d->dtype != IR2RGB_BF16 && d->dtype != IR2RGB_F16) return IR2RGB_ENOSUP;
+    if (d->pad_mode != 0 && d->pad_mode != 1) return IR2RGB_ENOSUP;   // pad_mode 2 exists in conv3x3_patch_kernel only
     int ncls = 0;
     long woff = 0;
     int row0 = 0;
@@ -873,9 +874,7 @@ static void launch_conv(const ClassPlan &c, const uint16_t *x, const uint16_t *w
 
 extern "C" int ir2rgb_conv2d_fwd(const ir2rgb_conv_desc *d, const void *x, const void *wpacked, const float *bias,
                                  void *y, float *stats_partial, void *stream) {
-    ClassPlan plans[4];
-    int n = make_plan(d, plans);
-    if (n < 0) return n;
+    if (!d) return IR2RGB_EINVAL;
     if ((((uintptr_t)x | (uintptr_t)wpacked | (uintptr_t)y) & 15) != 0) return IR2RGB_EALIGN;
     {
         P3Geom g3;
@@ -883,6 +882,9 @@ extern "C" int ir2rgb_conv2d_fwd(const ir2rgb_conv_desc *d, const void *x, const
         const int variant = conv3x3p_plan(d, &g3, &npt3);
         if (variant) return conv3x3p_launch(variant, g3, d->dtype, x, wpacked, bias, y, stats_partial, as_stream(stream));
     }
+    ClassPlan plans[4];
+    int n = make_plan(d, plans);
+    if (n < 0) return n;
     if (n > 1 && merge_classes()) {
         // one launch for all classes: same pixel-tile size for all of them (plans were made with it)
         ConvClasses cs;

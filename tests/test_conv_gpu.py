@@ -121,3 +121,37 @@ def test_hot_shape_linearity(dev):
     rms = ref.pow(2).mean().sqrt().item()
     assert ((got - ref).abs() <= 2.0 ** -8 * ref.abs() + 1e-2 * rms).all()
     torch.testing.assert_close(stats.sum(0)[0][idx] / 8192, ref.mean((0, 2, 3)), atol=2e-3 * rms, rtol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [
+    # N, forward Cout (= channels of gy), H, W, forward Cin
+    (1, 256, 100, 128, 256),     # 2x64 px x 64 cout tiles: every tile touches the left and right border
+    (1, 256, 100, 256, 256),     # 2x128 px x 128 cout tiles
+    (2, 320, 52, 64, 256),       # one column tile (left and right border in the same tile), batch 2, 5 K chunks
+])
+def test_reflect_adjoint_in_place(dev, dtype, case):
+    """pad_mode 2 of the patch-staged kernel: the data gradient of a reflection-padded 3x3 convolution computed
+    on the unpadded grid (border terms inside the kernel) vs torch autograd through F.pad(reflect) + conv2d on the
+    same half-rounded operands."""
+    from ir2rgb_amd import conv as C
+    n, cgy, h, w, cin = case
+    g = torch.Generator(device="cpu").manual_seed(cgy + h)
+    gy = torch.randn(n, cgy, h, w, generator=g).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(cgy, cin, 3, 3, generator=g) * (1.0 / np.sqrt(cgy * 9))).to(dev)
+    dadj = C.make_desc(gy.shape, cin, 3, 1, 1, C.PAD_REFLECT_ADJ, dtype)
+    assert C.kernel_name(dadj) == "conv3x3_patch_kernel"
+    wp = C.pack_weight(C.make_desc(gy.shape, cin, 3, 1, 1, C.PAD_ZERO, dtype), wt, adjoint=True)
+    dx, _ = C.conv2d_fwd(dadj, gy, wp)
+    x = torch.zeros(n, cin, h, w, device=dev, requires_grad=True)
+    y = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), wt.to(dtype).float())
+    (y * gy.float()).sum().backward()
+    ref = x.grad
+    rms = ref.pow(2).mean().sqrt().item()
+    rel, ab = (2.0 ** -8, 1e-2) if dtype == torch.bfloat16 else (2.0 ** -11, 2e-3)
+    err = (dx.float() - ref).abs()
+    bad = (err > rel * ref.abs() + ab * rms).sum().item()
+    assert bad == 0, f"{bad} elements out of tolerance; max err {err.max().item():.4g}, rms {rms:.4g}"
+    # the general kernel refuses the mode instead of computing something else
+    small = C.make_desc((1, 64, 8, 64), 64, 3, 1, 1, C.PAD_REFLECT_ADJ, dtype)
+    assert C.kernel_name(small) == ""
