@@ -240,7 +240,9 @@ class Vid2VidTrainer:
         for m in self.netG + [self.netD] + self.netD_T:
             m.to(device).train()
             m.compute_dtype = o["compute_dtype"]
-        self.flow_net = FlowNet(o["flownet_dtype"]).to(device)
+        # HIP-graph replay of FlowNet2 only in the single-process case: it saves host time, not GPU time, and
+        # graph capture next to RCCL's watchdog thread cannot be exercised on the one-GPU development box
+        self.flow_net = FlowNet(o["flownet_dtype"], use_graph=None if world_size == 1 else False).to(device)
         self._side_wgrad = None          # set per window in generate(): safe only when n_load == 1
 
         g_params = [p for g in self.netG for p in g.parameters()]  # niter_fix_global = 0: all scales train
