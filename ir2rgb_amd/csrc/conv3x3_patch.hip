@@ -64,20 +64,23 @@ __device__ __forceinline__ int p3_reflect(int v, int n) {
     return v >= n ? 2 * n - 2 - v : v;
 }
 
-template <int TW, int TCO, int NCW, int NLW, int ADJ> struct P3Cfg {
+// SPS = 32-channel slices per K-step (1 or 2): with 2, a step covers a whole 64-channel chunk at one ky --
+// twice the MFMA work between barriers for the small tile, whose steps are otherwise only 24 MFMAs long.
+template <int TW, int TCO, int NCW, int NLW, int ADJ, int SPS> struct P3Cfg {
     static constexpr int TR = 2, NPX = TR * TW;
     static constexpr int PWP = ((TW + 2 + 15) / 16) * 16;   // patch row pitch in entries (80 | 144)
     static constexpr int PROWI = PWP / 16;                   // DMA instructions per patch row
-    static constexpr int NW = 3 * TCO / 16;                  // DMA instructions for the weights of one K-step
-    static constexpr int WST = 3 * TCO * 64;                 // bytes per weight stage
-    static constexpr int PBUF = 4 * PWP * 64;                // bytes per patch buffer
-    static constexpr int NSTW = (TW == 128 && TCO == 128) ? 3 : 4;
+    static constexpr int NW1 = 3 * TCO / 16, NW = SPS * NW1; // DMA instructions for the weights of one K-step
+    static constexpr int WST1 = 3 * TCO * 64, WST = SPS * WST1;   // bytes per weight stage (per slice, per step)
+    static constexpr int PBUF = 4 * PWP * 64;                // bytes per patch buffer (one slice)
+    static constexpr int NSTW = (SPS == 2 || (TW == 128 && TCO == 128)) ? 3 : 4;
     static constexpr int AHEAD = NSTW - 1;
     static constexpr int WM = TCO / 64, WN = NCW / WM, PXW = NPX / WN, NI = PXW / 16;
-    static constexpr int LDS = NSTW * WST + 2 * PBUF + 1024;
+    static constexpr int LDS = NSTW * WST + 2 * SPS * PBUF + 1024;
     // patch rows staged with the step of phase ky: rows {0,1} | {2} | {3}; reflect-adjoint mode needs every row from
     // the first step on (its border terms read row 2 at ky = 0), so it stages all four with ky = 0
-    static constexpr int np(int ky) { return ADJ ? (ky == 0 ? 4 * PROWI : 0) : (ky == 0 ? 2 * PROWI : PROWI); }
+    static constexpr int np1(int ky) { return ADJ ? (ky == 0 ? 4 * PROWI : 0) : (ky == 0 ? 2 * PROWI : PROWI); }
+    static constexpr int np(int ky) { return SPS * np1(ky); }
     static constexpr int nl(int ky) { return (NW + np(ky) + NLW - 1) / NLW; }     // DMA instructions per loader wave
     static constexpr int NLMAX = nl(0);
     // DMA instructions a loader wave may leave in flight while step (phase ky) is consumed: the steps staged after it
@@ -88,17 +91,18 @@ template <int TW, int TCO, int NCW, int NLW, int ADJ> struct P3Cfg {
     }
 };
 
-template <int DT, int TW, int TCO, int NCW, int NLW, int PIPE, int ADJ>
+template <int DT, int TW, int TCO, int NCW, int NLW, int PIPE, int ADJ, int SPS>
 __global__ void __launch_bounds__((NCW + NLW) * 64, 1)
 conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Wp, const float *__restrict__ bias,
                      uint16_t *__restrict__ Y, float *__restrict__ stats_partial, const P3Geom g) {
-    typedef P3Cfg<TW, TCO, NCW, NLW, ADJ> C;
+    typedef P3Cfg<TW, TCO, NCW, NLW, ADJ, SPS> C;
+    static_assert(SPS == 1 || (PIPE && !ADJ), "two slices per step: pipelined forward form only");
     static_assert(!(ADJ && PIPE), "reflect-adjoint terms read the patch after the tap they belong to: plain loop only");
     typedef P3Half<DT> Hf;
     typedef typename Hf::frag frag;
     constexpr int NI = C::NI, MI = 4;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[C::LDS];
-    unsigned char *const wring = smem, *const pbufs = smem + C::NSTW * C::WST, *const dummy = pbufs + 2 * C::PBUF;
+    unsigned char *const wring = smem, *const pbufs = smem + C::NSTW * C::WST, *const dummy = pbufs + 2 * SPS * C::PBUF;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -116,7 +120,7 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
     else              { pt = tile / nct; ct = tile - pt * nct; }
     const int txi = pt % g.ntx, tyi = (pt / g.ntx) % g.nty, n = pt / (g.ntx * g.nty);
     const int y0 = tyi * C::TR, x0 = txi * TW;
-    const int NK = g.kchunks * 2 * 3;   // K-steps: (64-channel chunk, half, ky)
+    const int NK = g.kchunks * (2 / SPS) * 3;   // K-steps: (64-channel chunk, [half,] ky)
 
     p3_f32x4 acc[MI][NI];
 #pragma unroll
@@ -146,11 +150,11 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
                     // R & 15 == row16 in every region.
                     const int chunk = (lane & 3) ^ ((row16 >> 1) & 2);
                     if (id < C::NW) {
-                        const int row = id * 16 + row16, kx = row / TCO, col = row - kx * TCO;
+                        const int row = (id % C::NW1) * 16 + row16, kx = row / TCO, col = row - kx * TCO;
                         const int co = ct * TCO + col;
                         v = (unsigned)((((long)co * g.kchunks) * 9 + kx) * 128 + chunk * 16);
                     } else if (id < C::NW + C::np(ky)) {
-                        const int q = id - C::NW;
+                        const int q = (id - C::NW) % (C::np1(ky) > 0 ? C::np1(ky) : 1);
                         const int pr = ky == 0 ? q / C::PROWI : ky + 1;   // (ADJ: ky == 0 covers rows 0..3)
                         const int pc = (q % C::PROWI) * 16 + row16;
                         int iy = y0 - g.pad + pr, ix = x0 - g.pad + pc;
@@ -165,22 +169,25 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
         int is = 0;   // next K-step to stage
         auto issue = [&]<int KY>(std::integral_constant<int, KY>) {
             const bool live = is < NK;
-            const int hs = is / 3;                       // 32-channel slice index (KY == is % 3 by construction)
-            const int cc = hs >> 1, half = hs & 1;
-            const unsigned w_soff = (unsigned)((cc * 9 + KY * 3) * 128 + half * 64);
-            const unsigned x_soff = (unsigned)((cc * 64 + half * 32) * 2);
+            const int hs = is / 3;                       // slice (SPS == 1) or 64-channel chunk (SPS == 2) of this step
+            const int cc = SPS == 2 ? hs : hs >> 1, half0 = SPS == 2 ? 0 : hs & 1;
+            const unsigned w_soff = (unsigned)((cc * 9 + KY * 3) * 128 + half0 * 64);
+            const unsigned x_soff = (unsigned)((cc * 64 + half0 * 32) * 2);
             unsigned char *wdst = wring + (is % C::NSTW) * C::WST;
-            unsigned char *pdst = pbufs + (hs & 1) * C::PBUF;
+            unsigned char *pdst = pbufs + (hs & 1) * SPS * C::PBUF;
 #pragma unroll
             for (int j = 0; j < C::nl(KY); ++j) {
                 const int id = lw + NLW * j;             // wave-uniform
                 const unsigned v = live ? voff[KY][j] : P3_OOB;
                 if (id < C::NW) {
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (p3_lptr_t)(wdst + id * 1024), 16, v, w_soff, 0, 0);
+                    const unsigned hoff = (unsigned)(id / C::NW1) * 64u;       // second slice of the step: +32 channels
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (p3_lptr_t)(wdst + id * 1024), 16, v, w_soff + hoff, 0, 0);
                 } else if (id < C::NW + C::np(KY)) {
-                    const int q = id - C::NW;
+                    constexpr int NP1 = C::np1(KY) > 0 ? C::np1(KY) : 1;
+                    const int qq = id - C::NW, h = qq / NP1, q = qq - h * NP1;
                     const int slot = KY == 0 ? q : (KY + 1) * C::PROWI + q;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (p3_lptr_t)(pdst + slot * 1024), 16, v, x_soff, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (p3_lptr_t)(pdst + h * C::PBUF + slot * 1024), 16, v,
+                                                             x_soff + (unsigned)h * 64u, 0, 0);
                 } else {
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (p3_lptr_t)dummy, 16, P3_OOB, 0, 0, 0);
                 }
@@ -191,7 +198,7 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
         issue(std::integral_constant<int, 0>{});
         if constexpr (C::AHEAD >= 2) issue(std::integral_constant<int, 1>{});
         if constexpr (C::AHEAD >= 3) issue(std::integral_constant<int, 2>{});
-        for (int hs = 0; hs < g.kchunks * 2; ++hs) {
+        for (int hs = 0; hs < NK / 3; ++hs) {
             auto step = [&]<int KY>(std::integral_constant<int, KY>) {
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::out(KY)) : "memory");   // this step's operands have landed
                 __builtin_amdgcn_s_barrier();                                         // ... and the previous step is consumed
@@ -267,7 +274,43 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
                 if (KY == 0 && kx == 0 && bot && right && ty == 0 && tx == TW - 16) term(2 * C::PWP * 64, 2, 14);
             }
         };
-        if constexpr (PIPE) {
+        if constexpr (PIPE && SPS == 2) {
+            // a step = one ky of a whole 64-channel chunk: six taps (slice, kx); tap t lives in fragment buffer t & 1,
+            // the barrier that opens the next step sits before the MFMAs of the last tap (see below)
+            int ks = 0;
+            __builtin_amdgcn_s_barrier();                       // step 0 has landed
+            fetch(0, wring, pbufs, 0, 0);
+            for (int cc = 0; cc < g.kchunks; ++cc) {
+                const unsigned char *patch = pbufs + (cc & 1) * 2 * C::PBUF;
+                const unsigned char *patch_next = pbufs + ((cc + 1) & 1) * 2 * C::PBUF;
+                auto step = [&]<int KY>(std::integral_constant<int, KY>) {
+                    const unsigned char *wst = wring + (ks % C::NSTW) * C::WST;
+                    const unsigned char *wst_next = wring + ((ks + 1) % C::NSTW) * C::WST;
+                    constexpr int KO = KY * C::PWP * 64;
+                    fetch(1, wst, patch, KO, 1);
+                    mma(0);
+                    fetch(0, wst, patch, KO, 2);
+                    mma(1);
+                    fetch(1, wst + C::WST1, patch + C::PBUF, KO, 0);
+                    mma(0);
+                    fetch(0, wst + C::WST1, patch + C::PBUF, KO, 1);
+                    mma(1);
+                    fetch(1, wst + C::WST1, patch + C::PBUF, KO, 2);
+                    mma(0);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read of step ks is complete
+                    if (ks + 1 < NK) {
+                        __builtin_amdgcn_s_barrier();            // step ks+1 has landed; stage ks may be overwritten
+                        if constexpr (KY < 2) fetch(0, wst_next, patch, (KY + 1) * C::PWP * 64, 0);
+                        else fetch(0, wst_next, patch_next, 0, 0);
+                    }
+                    mma(1);
+                    ++ks;
+                };
+                step(std::integral_constant<int, 0>{});
+                step(std::integral_constant<int, 1>{});
+                step(std::integral_constant<int, 2>{});
+            }
+        } else if constexpr (PIPE) {
             int ks = 0;
             __builtin_amdgcn_s_barrier();                       // step 0 has landed
             fetch(0, wring, pbufs, 0, 0);
@@ -394,6 +437,16 @@ static bool p3_enabled() {
     return v != 0;
 }
 
+// Small tile with one 64-channel chunk per K-step instead of one 32-channel slice (half the barriers).  Measured
+// neutral (51.7 / 54.0 us against 53.7 / 53.9 us): the 2x64 px x 64 cout tile is bound by LDS bandwidth, not by the
+// barrier cadence -- four waves each read all 64 couts' weights for only 32 pixels: 0.75 KB of ds_read_b128 per MFMA
+// = 192 B/clk of the 256 B/clk LDS, plus the DMA writes.  Kept selectable (IR2RGB_CONV3X3P_SPS2=1), off by default.
+static bool p3_sps2() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("IR2RGB_CONV3X3P_SPS2"); v = e ? atoi(e) : 0; }
+    return v != 0;
+}
+
 static long p3_min_tiles() {   // fewer tiles than this leave too much of the chip idle: the general kernel runs instead
     static long v = -1;
     if (v < 0) { const char *e = getenv("IR2RGB_CONV3X3P_MIN_TILES"); v = e ? atol(e) : 200; }
@@ -452,20 +505,25 @@ int conv3x3p_launch(int variant, const P3Geom &g, int dtype, const void *x, cons
     if (variant == 2) {
         const unsigned grid = (unsigned)(npt * (g.Cout / 128));
         if (adj) {
-            if (dtype == IR2RGB_BF16) conv3x3_patch_kernel<IR2RGB_BF16, 128, 128, 8, 4, 0, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
-            else conv3x3_patch_kernel<IR2RGB_F16, 128, 128, 8, 4, 0, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+            if (dtype == IR2RGB_BF16) conv3x3_patch_kernel<IR2RGB_BF16, 128, 128, 8, 4, 0, 1, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+            else conv3x3_patch_kernel<IR2RGB_F16, 128, 128, 8, 4, 0, 1, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
         } else {
-            if (dtype == IR2RGB_BF16) conv3x3_patch_kernel<IR2RGB_BF16, 128, 128, 8, 4, 0, 0><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
-            else conv3x3_patch_kernel<IR2RGB_F16, 128, 128, 8, 4, 0, 0><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+            if (dtype == IR2RGB_BF16) conv3x3_patch_kernel<IR2RGB_BF16, 128, 128, 8, 4, 0, 0, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+            else conv3x3_patch_kernel<IR2RGB_F16, 128, 128, 8, 4, 0, 0, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
         }
     } else {
         const unsigned grid = (unsigned)(npt * (g.Cout / 64));
         if (adj) {
-            if (dtype == IR2RGB_BF16) conv3x3_patch_kernel<IR2RGB_BF16, 64, 64, 4, 8, 0, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
-            else conv3x3_patch_kernel<IR2RGB_F16, 64, 64, 4, 8, 0, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+            if (dtype == IR2RGB_BF16) conv3x3_patch_kernel<IR2RGB_BF16, 64, 64, 4, 8, 0, 1, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+            else conv3x3_patch_kernel<IR2RGB_F16, 64, 64, 4, 8, 0, 1, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
         } else {
-            if (dtype == IR2RGB_BF16) conv3x3_patch_kernel<IR2RGB_BF16, 64, 64, 4, 8, 1, 0><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
-            else conv3x3_patch_kernel<IR2RGB_F16, 64, 64, 4, 8, 1, 0><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+            if (p3_sps2()) {
+                if (dtype == IR2RGB_BF16) conv3x3_patch_kernel<IR2RGB_BF16, 64, 64, 4, 8, 1, 0, 2><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+                else conv3x3_patch_kernel<IR2RGB_F16, 64, 64, 4, 8, 1, 0, 2><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+            } else {
+                if (dtype == IR2RGB_BF16) conv3x3_patch_kernel<IR2RGB_BF16, 64, 64, 4, 8, 1, 0, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+                else conv3x3_patch_kernel<IR2RGB_F16, 64, 64, 4, 8, 1, 0, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+            }
         }
     }
     return ir2rgb_launch_status();
