@@ -155,3 +155,31 @@ def test_reflect_adjoint_in_place(dev, dtype, case):
     # the general kernel refuses the mode instead of computing something else
     small = C.make_desc((1, 64, 8, 64), 64, 3, 1, 1, C.PAD_REFLECT_ADJ, dtype)
     assert C.kernel_name(small) == ""
+
+
+def test_full_size_adjoint_identities(dev):
+    """BASELINE config-2 bottleneck layer at full size (1024 -> 1024 channels, 3x3 reflect, 32x64 pixels), checked
+    through the adjoint identities that tie the three kernels of a layer together without a CPU-sized oracle:
+        <conv(x; W), g>  ==  <x, dgrad(g; W)>  ==  <W, wgrad(x, g)>
+    with conv = patch-staged forward, dgrad = its in-place reflection adjoint (pad_mode 2), wgrad = the nine-tap
+    weight-gradient kernel.  The three sums of 2M..9M products agree to the rounding of the half outputs."""
+    from ir2rgb_amd import conv as C
+    dt = torch.bfloat16
+    gen = torch.Generator(device="cpu").manual_seed(21)
+    x = torch.randn(1, 1024, 32, 64, generator=gen).to(dev).to(dt).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(1, 1024, 32, 64, generator=gen).to(dev).to(dt).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(1024, 1024, 3, 3, generator=gen) * 0.01).to(dev).to(dt).float()    # exactly representable weights
+    dfwd = C.make_desc(x.shape, 1024, 3, 1, 1, C.PAD_REFLECT, dt)
+    assert C.kernel_name(dfwd) == "conv3x3_patch_kernel"
+    y, _ = C.conv2d_fwd(dfwd, x, C.pack_weight(dfwd, w))
+    dadj = C.make_desc(gy.shape, 1024, 3, 1, 1, C.PAD_REFLECT_ADJ, dt)
+    assert C.kernel_name(dadj) == "conv3x3_patch_kernel"
+    dx, _ = C.conv2d_fwd(dadj, gy, C.pack_weight(C.make_desc(gy.shape, 1024, 3, 1, 1, C.PAD_ZERO, dt), w, adjoint=True))
+    dw = C.conv2d_wgrad(dfwd, x, gy)
+    a = (y.double() * gy.double()).sum().item()
+    b = (x.double() * dx.double()).sum().item()
+    c = (w.double() * dw.double()).sum().item()
+    scale = (y.double().pow(2).sum().sqrt() * gy.double().pow(2).sum().sqrt()).item()   # Cauchy-Schwarz scale of the sums
+    # y and dx are rounded to bf16 (2^-9 relative per element, random signs over 2M terms); dw is fp32
+    assert abs(a - c) <= 2e-4 * scale, (a, c, scale)
+    assert abs(b - c) <= 2e-4 * scale, (b, c, scale)
