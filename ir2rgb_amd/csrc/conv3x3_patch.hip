@@ -22,7 +22,7 @@
 // gather offsets are constants of the workgroup's tile, the slice offset rides in an SGPR); one
 // s_barrier and one counted vmcnt per K-step; weights in an NSTW-stage ring, the patch double-buffered.
 // Epilogue: bias, LeakyReLU, per-tile BatchNorm partial sums (same [tiles][2][Cout] contract as
-// conv_igemm_kernel), half stores of 4 consecutive couts per lane.
+// conv_igemm_kernel), half outputs staged through LDS and written as 16-byte stores.
 #include <utility>
 
 #include "common.h"
@@ -372,14 +372,21 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
     }
 
     // ---------------- epilogue ----------------
+    // bias + activation + BatchNorm partial sums from the accumulators; the half outputs go through LDS
+    // ([pixel][TCO couts], 16-byte chunk c of pixel row p at position c ^ (p & (TCO/8 - 1)): conflict-free both ways)
+    // so that global memory sees 16-byte stores, TCO/8 lanes per contiguous TCO*2-byte pixel row, instead of 8-byte
+    // pieces 2 KB apart.
     __builtin_amdgcn_s_barrier();   // every wave is past its last LDS read / its last DMA has landed: smem is reusable
-    float *red = reinterpret_cast<float *>(smem);   // [WN][TCO][2]
+    constexpr int NCH = TCO / 8;                                    // 16-byte chunks per staged pixel row
+    unsigned char *otile = smem;                                    // NPX * TCO * 2 bytes
+    float *red = reinterpret_cast<float *>(smem + C::NPX * TCO * 2);   // [WN][TCO][2]
+    static_assert(C::NPX * TCO * 2 + C::WN * TCO * 2 * 4 <= C::LDS, "epilogue staging exceeds the ring");
     if (!loader) {
         const int wm = wave / C::WN, wn = wave - wm * C::WN;
         const int l15 = lane & 15, grp = lane >> 4;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-            const int cl = wm * 64 + mi * 16 + grp * 4;      // cout within the tile
+            const int cl = wm * 64 + mi * 16 + grp * 4;      // cout within the tile (multiple of 4)
             const int co = ct * TCO + cl;
             float bv[4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -396,12 +403,10 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
                     if (g.act) v[r] = v[r] > 0.f ? v[r] : (g.act == 1 ? 0.2f : 0.1f) * v[r];
                     if (valid) { s1[r] += v[r]; s2[r] += v[r] * v[r]; }
                 }
-                if (valid) {
-                    uint2 pk;
-                    pk.x = (uint32_t)Hf::cvt(v[0]) | ((uint32_t)Hf::cvt(v[1]) << 16);
-                    pk.y = (uint32_t)Hf::cvt(v[2]) | ((uint32_t)Hf::cvt(v[3]) << 16);
-                    *reinterpret_cast<uint2 *>(Y + (((long)n * g.Ho + oy) * g.Wo + ox) * g.ldy + g.co_off + co) = pk;
-                }
+                uint2 pk;
+                pk.x = (uint32_t)Hf::cvt(v[0]) | ((uint32_t)Hf::cvt(v[1]) << 16);
+                pk.y = (uint32_t)Hf::cvt(v[2]) | ((uint32_t)Hf::cvt(v[3]) << 16);
+                *reinterpret_cast<uint2 *>(otile + p * (TCO * 2) + (((cl >> 3) ^ (p & (NCH - 1))) << 4) + (cl & 4) * 2) = pk;
             }
             if (stats_partial != nullptr) {
 #pragma unroll
@@ -416,9 +421,20 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
             }
         }
     }
-    if (stats_partial != nullptr) {
-        __builtin_amdgcn_s_barrier();
-        if (tid < TCO * 2) {   // tid < 256: the multiplying waves
+    __builtin_amdgcn_s_barrier();
+    {
+        // every thread of the workgroup (loader waves included) copies 16-byte chunks: NCH lanes per pixel row
+        constexpr int NT = (NCW + NLW) * 64;
+        const int c16 = tid % NCH;
+        for (int p = tid / NCH; p < C::NPX; p += NT / NCH) {
+            const int ty = p / TW, tx = p - ty * TW;
+            const int oy = y0 + ty, ox = x0 + tx;
+            if (oy < g.Ho && ox < g.Wo) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(otile + p * (TCO * 2) + ((c16 ^ (p & (NCH - 1))) << 4));
+                *reinterpret_cast<uint4 *>(Y + (((long)n * g.Ho + oy) * g.Wo + ox) * g.ldy + g.co_off + ct * TCO + c16 * 8) = v;
+            }
+        }
+        if (stats_partial != nullptr && tid < TCO * 2) {
             const int cl = tid >> 1, which = tid & 1;
             float t = 0.f;
 #pragma unroll
@@ -470,7 +486,7 @@ int conv3x3p_plan(const ir2rgb_conv_desc *d, P3Geom *g, int *npt_out) {
     if ((d->Cin % 64) || d->Cin < p3_min_cin() || (d->Cout % 64) || d->Hin < 4 || d->Win < 4 || d->N < 1) return 0;
     if (d->dtype != IR2RGB_BF16 && d->dtype != IR2RGB_F16) return 0;
     const int ldx = d->ldx > 0 ? d->ldx : d->Cin, ldy = d->ldy > 0 ? d->ldy : d->Cout;
-    if ((ldx & 7) || (d->ci_off & 7) || (ldy & 3) || (d->co_off & 3)) return 0;
+    if ((ldx & 7) || (d->ci_off & 7) || (ldy & 7) || (d->co_off & 7)) return 0;   // 16-byte loads and stores
     const long xb = (long)d->N * d->Hin * d->Win * ldx * 2, wb = (long)d->Cout * d->Cin * 9 * 2;
     if (xb >= (1L << 31) || wb >= (1L << 31)) return 0;
     auto waste = [](int n, int t) { return (double)(((n + t - 1) / t) * t) / n; };
