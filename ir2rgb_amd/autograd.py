@@ -165,18 +165,26 @@ def conv_wgrad(x, gy, weight_shape, spec):
 
 
 # ---------------------------------------------------------------------------------------------
-# weight gradients on a second HIP stream.  The data-gradient chain (dgrad conv -> fold -> BN
-# backward of the layer below) is the critical path of loss.backward(); the weight gradient of a
-# layer only feeds the optimizer, so it runs beside that chain and fills the CUs the chain's small
-# launches leave idle.  This is only sound for a parameter that is used ONCE per backward pass:
-# autograd then hands the tensor to AccumulateGrad untouched.  A parameter used by several nodes has
-# its contributions summed by the engine on the main stream, which knows nothing of the side stream
-# (measured: discriminator gradients, 3 uses per pass, came out wrong).  So the side stream is opt-in
-# per module tree (enable_side_wgrad: the trainer turns it on for the generators, each called once
-# per window) and never used while the parameter already holds a gradient.  The side stream is joined
-# when the backward pass ends (engine callback).
+# weight gradients on a second HIP stream (OFF by default since the nine-tap weight-gradient kernel: see below).
+# The data-gradient chain (dgrad conv -> BN backward of the layer below) is the critical path of
+# loss.backward(); the weight gradient of a layer only feeds the optimizer, so it can run beside that chain
+# and fill the CUs the chain's small launches leave idle.  This is only sound for a parameter that is used
+# ONCE per backward pass: autograd then hands the tensor to AccumulateGrad untouched.  A parameter used by
+# several nodes has its contributions summed by the engine on the main stream, which knows nothing of the
+# side stream (measured: discriminator gradients, 3 uses per pass, came out wrong).  So the side stream is
+# opt-in per module tree (enable_side_wgrad: the trainer marks the generators, each called once per window)
+# and never used while the parameter already holds a gradient.  The side stream is joined when the backward
+# pass ends (engine callback).
+# Measured: with the one-tap weight-gradient kernel (126 us, half of the chip idle) the overlap saved 2 ms per
+# window; with the nine-tap kernel (44 us, every CU busy) it COSTS 1.7 ms (44.2 vs 42.5 ms per window): the
+# overlapped kernels slow the critical chain and the stream hand-offs add bubbles -- also when only the
+# remaining one-tap launches use the side stream (IR2RGB_WGRAD_STREAM=2: 44.3 ms).  Hence default off
+# (IR2RGB_WGRAD_STREAM=1 enables it; tests/test_losses_gpu.py keeps it covered).
 # ---------------------------------------------------------------------------------------------
-WGRAD_SIDE_STREAM = os.environ.get("IR2RGB_WGRAD_STREAM", "1") != "0"
+WGRAD_SIDE_STREAM = os.environ.get("IR2RGB_WGRAD_STREAM", "0") != "0"
+# "2": only weight gradients that do NOT fill the chip (strided / transposed / first layers, one-tap kernel) go to the
+# side stream; the nine-tap kernel of the residual blocks occupies every CU and slows the data-gradient chain it overlaps
+WGRAD_SIDE_SMALL_ONLY = os.environ.get("IR2RGB_WGRAD_STREAM", "0") == "2"
 _SIDE = {}
 
 
@@ -201,6 +209,9 @@ def wgrad_overlapped(conv, fn, *inputs):
     dev = inputs[0].device
     param = conv.weight
     if not WGRAD_SIDE_STREAM or dev.type != "cuda" or not getattr(conv, "_ir2rgb_side_wgrad", False):
+        return fn()
+    if WGRAD_SIDE_SMALL_ONLY and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1) and \
+            not isinstance(conv, torch.nn.ConvTranspose2d) and conv.in_channels >= 64:
         return fn()
     st = _SIDE.get(dev.index)
     if st is None:

@@ -143,6 +143,7 @@ def test_side_stream_weight_gradients_change_nothing():
     dev = _dev()
     A, B = V.synthetic_sequence(4, 64, 128, 7, dev)
     grads = []
+    default = AG.WGRAD_SIDE_STREAM
     for side in (True, False):
         AG.WGRAD_SIDE_STREAM = side
         try:
@@ -154,7 +155,7 @@ def test_side_stream_weight_gradients_change_nothing():
             torch.cuda.synchronize()
             grads.append(([p.grad.clone() for p in tr.grads_G.params], [p.grad.clone() for p in tr.grads_D.params]))
         finally:
-            AG.WGRAD_SIDE_STREAM = True
+            AG.WGRAD_SIDE_STREAM = default
     for a, b in zip(grads[0][1], grads[1][1]):
         assert torch.equal(a, b)
     for a, b in zip(grads[0][0], grads[1][0]):
