@@ -9,11 +9,12 @@ cin = cout = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 h, w = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (64, 128)
 x = torch.randn(1, cin, h, w, device=dev).to(dt).contiguous(memory_format=torch.channels_last)
 wt = torch.randn(cout, cin, 3, 3, device=dev) * 0.02
-d = C.make_desc(x.shape, cout, 3, 1, 1, 1, dt)
-wp = C.pack_weight(d, wt)
+adj = len(sys.argv) > 4 and sys.argv[4] == "adj"     # the in-place reflect adjoint (data gradient) of the same layer
+d = C.make_desc(x.shape, cout, 3, 1, 1, C.PAD_REFLECT_ADJ if adj else C.PAD_REFLECT, dt)
+wp = C.pack_weight(C.make_desc(x.shape, cout, 3, 1, 1, 0, dt), wt, adjoint=True) if adj else C.pack_weight(d, wt)
 y = C.empty_nhwc(1, cout, h, w, dt, dev)
 b = torch.zeros(cout, device=dev)
 for _ in range(20):
-    C.conv2d_fwd(d, x, wp, b, want_stats=True, out=y)
+    C.conv2d_fwd(d, x, wp, None if adj else b, want_stats=not adj, out=y)
 torch.cuda.synchronize()
 print("done")
