@@ -254,24 +254,48 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
         //     F(y, W)   = sum_sy Wf(sy, -1) gy(y+sy, W-1)  -> pixel tx = TW-2, weights kx = 0, the entry of kx = 2
         //   so the padded 34 x 66 output grid and the fold pass disappear.  (H even, W % TW == 0: whole tiles.)
         const bool top = y0 == 0, bot = y0 == g.H - 2, left = x0 == 0, right = x0 + TW == g.W;
-        auto border_terms = [&]<int KY>(const unsigned char *patch, std::integral_constant<int, KY>, int kx) {
+        // The border operands of a step are fetched right after its barrier (their LDS latency then hides under the
+        // regular taps; fetched at the point of use they cost a full LDS round trip per term on a wave that has its
+        // SIMD to itself: 67.6 -> see profiles) and multiplied after the tap whose weights they use.
+        constexpr bool PRE = NI <= 2;   // (the large tile has two waves per SIMD to hide the latency and no registers to spare)
+        frag eb_row[3][PRE ? NI : 1], eb_l[PRE ? NI : 1], eb_r[PRE ? NI : 1];
+        auto entry = [&](const unsigned char *patch, int ni, int kyoff, int kxb) -> frag {
+            return *reinterpret_cast<const frag *>(patch + (bofs[ni] ^ (kxb == 0 ? 0u : (kxb == 1 ? flip1 : flip2))) + kxb * 64 + kyoff);
+        };
+        auto prefetch_terms = [&]<int KY>(const unsigned char *patch, std::integral_constant<int, KY>) {
+            if constexpr (PRE) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int p = wn * C::PXW + ni * 16, ty = p / TW, tx = p - ty * TW;   // wave-uniform
+                    const bool rowterm = (KY == 2 && top && ty == 1) || (KY == 0 && bot && ty == 0);
+                    if (rowterm) {
+                        const int kyoff = KY == 2 ? 0 : 2 * C::PWP * 64;
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) eb_row[kx][ni] = entry(patch, ni, kyoff, kx);
+                    }
+                    if (left && tx == 0) eb_l[ni] = entry(patch, ni, KY * C::PWP * 64, 0);
+                    if (right && tx == TW - 16) eb_r[ni] = entry(patch, ni, KY * C::PWP * 64, 2);
+                }
+            }
+        };
+        auto border_terms = [&]<int KY>(const unsigned char *patch, std::integral_constant<int, KY>, int kx, int abuf) {
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
                 const int p = wn * C::PXW + ni * 16, ty = p / TW, tx = p - ty * TW;   // wave-uniform
-                auto term = [&](int kyoff, int kxb, int only_lane) {
-                    frag b = *reinterpret_cast<const frag *>(patch + (bofs[ni] ^ (kxb == 0 ? 0u : (kxb == 1 ? flip1 : flip2))) + kxb * 64 + kyoff);
+                auto term = [&](frag b, int only_lane) {
                     if (only_lane >= 0 && l15 != only_lane) b = frag{};
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = Hf::mfma(fa[0][mi], b, acc[mi][ni]);
+                    for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = Hf::mfma(fa[abuf][mi], b, acc[mi][ni]);
                 };
-                if (KY == 2 && top && ty == 1) term(0, kx, -1);
-                if (KY == 0 && bot && ty == 0) term(2 * C::PWP * 64, kx, -1);
-                if (kx == 2 && left && tx == 0) term(KY * C::PWP * 64, 0, 1);
-                if (kx == 0 && right && tx == TW - 16) term(KY * C::PWP * 64, 2, 14);
-                if (KY == 2 && kx == 2 && top && left && ty == 1 && tx == 0) term(0, 0, 1);
-                if (KY == 2 && kx == 0 && top && right && ty == 1 && tx == TW - 16) term(0, 2, 14);
-                if (KY == 0 && kx == 2 && bot && left && ty == 0 && tx == 0) term(2 * C::PWP * 64, 0, 1);
-                if (KY == 0 && kx == 0 && bot && right && ty == 0 && tx == TW - 16) term(2 * C::PWP * 64, 2, 14);
+                const bool rowterm = (KY == 2 && top && ty == 1) || (KY == 0 && bot && ty == 0);
+                const int rowoff = KY == 2 ? 0 : 2 * C::PWP * 64;
+                constexpr int pi = PRE ? 1 : 0;   // index helper: prefetched arrays are per ni only when PRE
+                if (rowterm) term(PRE ? eb_row[kx][ni * pi] : entry(patch, ni, rowoff, kx), -1);
+                if (kx == 2 && left && tx == 0) term(PRE ? eb_l[ni * pi] : entry(patch, ni, KY * C::PWP * 64, 0), 1);
+                if (kx == 0 && right && tx == TW - 16) term(PRE ? eb_r[ni * pi] : entry(patch, ni, KY * C::PWP * 64, 2), 14);
+                // corners: the row-term entry of the other tap, one lane only
+                if (rowterm && kx == 2 && left && tx == 0) term(PRE ? eb_row[0][ni * pi] : entry(patch, ni, rowoff, 0), 1);
+                if (rowterm && kx == 0 && right && tx == TW - 16) term(PRE ? eb_row[2][ni * pi] : entry(patch, ni, rowoff, 2), 14);
             }
         };
         if constexpr (PIPE && SPS == 2) {
@@ -356,11 +380,12 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
                 auto step = [&]<int KY>(std::integral_constant<int, KY>) {
                     __builtin_amdgcn_s_barrier();
                     const unsigned char *wst = wring + (ks % C::NSTW) * C::WST;
+                    if constexpr (ADJ) prefetch_terms(patch, std::integral_constant<int, KY>{});
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         fetch(0, wst, patch, KY * C::PWP * 64, kx);
                         mma(0);
-                        if constexpr (ADJ) border_terms(patch, std::integral_constant<int, KY>{}, kx);
+                        if constexpr (ADJ) border_terms(patch, std::integral_constant<int, KY>{}, kx, 0);
                     }
                     ++ks;
                 };
