@@ -122,7 +122,7 @@ typedef struct ir2rgb_conv_desc {
                              * grid + ir2rgb_fold_reflect) */
     int transposed;         /* 0: Conv2d, 1: ConvTranspose2d (stride 1 or 2 per axis; Hout/Wout carry output_padding) */
     int dtype;              /* IR2RGB_BF16 or IR2RGB_F16: activations and packed weights */
-    int act;                /* fused after bias: 0 none, 1 LeakyReLU(0.2), 2 LeakyReLU(0.1) */
+    int act;                /* fused after bias: 0 none, 1 LeakyReLU(0.2), 2 LeakyReLU(0.1), 3 ReLU */
     int out_f32;            /* 0: y is half NHWC, 1: y is fp32 NHWC (head convolutions) */
     /* channel-slice views (0 = dense): x holds ldx channels per pixel of which [ci_off, ci_off+Cin) are
      * read; y holds ldy channels per pixel of which [co_off, co_off+Cout) are written.  Lets producers

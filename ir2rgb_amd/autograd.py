@@ -262,6 +262,11 @@ def backward_flags(modules, flags):
 # ---------------------------------------------------------------------------------------------
 # the fused stage
 # ---------------------------------------------------------------------------------------------
+def _fused_act(spec):
+    """Activation fused into the convolution epilogue of a stage WITHOUT BatchNorm (ir2rgb_conv_desc.act)."""
+    return 1 if spec["fused_leaky"] else (3 if spec.get("fused_relu") else 0)
+
+
 class ConvStageFn(Function):
     """z = act(bn(conv(x))) + res1 + res2 on channels_last half tensors (x may be an NCHW fp32 image
     for 'first' stages).  Arguments after ``x``: weight, bias, gamma, beta (fp32 parameters), res1,
@@ -276,12 +281,12 @@ class ConvStageFn(Function):
             kh, kw = conv.kernel_size
             xin = L.xexpand(x, kw, spec["stride"][1], spec["pad"][1], spec["pad_mode"], dt)
             desc = C.make_desc(tuple(xin.shape), conv.out_channels, (kh, 1), (spec["stride"][0], 1), (spec["pad"][0], 0),
-                               spec["pad_mode"], dt, act=1 if spec["fused_leaky"] else 0)
+                               spec["pad_mode"], dt, act=_fused_act(spec))
             wp = L.packed_weight(conv, desc, L._xexpanded_weight(kw), tag="xexp")
         else:
             xin = x
             desc = C.make_desc(tuple(x.shape), conv.out_channels, spec["k"], spec["stride"], spec["pad"], spec["pad_mode"],
-                               dt, spec["transposed"], spec.get("output_padding", 0), act=1 if spec["fused_leaky"] else 0,
+                               dt, spec["transposed"], spec.get("output_padding", 0), act=_fused_act(spec),
                                out_f32=spec.get("out_f32", False))
             wp = L.packed_weight(conv, desc)
         y, stats = C.conv2d_fwd(desc, xin, wp, bias, want_stats=bn is not None)
@@ -324,7 +329,8 @@ class ConvStageFn(Function):
             dbias = None  # BatchNorm removes the per-channel mean: the bias gradient is exactly 0
         else:
             gz = _as_half_nhwc(gz, hdt)
-            act = 2 if spec["fused_leaky"] else 0  # LeakyReLU keeps the sign: mask from the stored output
+            # LeakyReLU / ReLU keep the sign (ReLU: y > 0 <=> pre-activation > 0): mask from the stored output
+            act = 2 if spec["fused_leaky"] else (1 if spec.get("fused_relu") else 0)
             gy, _, dbias = bn_bwd(gz, y, None, None, None, None, act)
             gy_thin = gy
             dgamma = dbeta = None
@@ -364,12 +370,12 @@ class ConvStageFn(Function):
 
 
 def conv_stage(x, conv, bn, act, pad_mode, dtype, *, first=False, stride=None, pad=None, transposed=False,
-               output_padding=0, res1=None, res2=None, fused_leaky=False, training=True, out_f32=False):
+               output_padding=0, res1=None, res2=None, fused_leaky=False, training=True, out_f32=False, fused_relu=False):
     """Autograd-aware stage: act(bn(conv(x))) + res1 + res2 (bn may be None)."""
     stride = tuple(conv.stride) if stride is None else C._pair(stride)
     pad = tuple(conv.padding) if pad is None else C._pair(pad)
     spec = dict(k=tuple(conv.kernel_size), stride=stride, pad=pad, pad_mode=pad_mode, transposed=transposed,
-                output_padding=output_padding, act=act, fused_leaky=fused_leaky, training=training, dtype=dtype,
+                output_padding=output_padding, act=act, fused_leaky=fused_leaky, fused_relu=fused_relu, training=training, dtype=dtype,
                 first=first, out_f32=out_f32)
     gamma = bn.weight if bn is not None else None
     beta = bn.bias if bn is not None else None

@@ -373,7 +373,7 @@ conv_igemm_body(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Wp,
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 v[r] = acc[mi][ni][r] + bv[r];
-                if (g.act) v[r] = v[r] > 0.f ? v[r] : (g.act == 1 ? 0.2f : 0.1f) * v[r];
+                if (g.act) v[r] = v[r] > 0.f ? v[r] : (g.act == 1 ? 0.2f : (g.act == 2 ? 0.1f : 0.f)) * v[r];
                 if (oval[ni]) { s1[r] += v[r]; s2[r] += v[r] * v[r]; }
             }
             if (staged) {

@@ -31,6 +31,8 @@ DEFAULTS = dict(  # options/base_options.py, options/train_options.py (SURVEY se
     feat_num=3, first_layer_dis_filters=64, num_D=2, n_layers_D=3, no_ganFeat=False, n_frames_D=3, n_scales_temporal=2,
     lr=2e-4, beta1=0.5, lambda_feat=10.0, lambda_T=10.0, lambda_F=10.0, no_first_img=False, max_frames_per_gpu=1,
     n_frames_bp=1, compute_dtype=torch.bfloat16, flownet_dtype=torch.bfloat16,
+    no_vgg=True,         # VGG19 perceptual loss off: the pretrained weights cannot be downloaded here (False: ir2rgb_amd.vgg,
+                         # randomly initialised unless a torchvision state_dict is loaded into trainer.vgg_loss.vgg)
     shared_fake_forward=True,   # one netD forward on generated frames serves the D and the G loss (autograd.backward_flags)
     fused_adam=True,     # one-launch HIP Adam (ir2rgb_amd.optim); False = torch.optim.Adam(foreach=True)
     fused_losses=True,   # grouped HIP loss kernels (ir2rgb_amd.losses); False = the same terms through torch ops
@@ -244,6 +246,11 @@ class Vid2VidTrainer:
         # graph capture next to RCCL's watchdog thread cannot be exercised on the one-GPU development box
         self.flow_net = FlowNet(o["flownet_dtype"], use_graph=None if world_size == 1 else False).to(device)
         self._side_wgrad = None          # set per window in generate(): safe only when n_load == 1
+        self.vgg_loss = None
+        if not o["no_vgg"]:
+            from .vgg import VGGLoss
+            self.vgg_loss = VGGLoss().to(device)
+            self.vgg_loss.vgg.compute_dtype = o["compute_dtype"]
 
         g_params = [p for g in self.netG for p in g.parameters()]  # niter_fix_global = 0: all scales train
         # NOT fused=True: torch's fused Adam updates the parameters without bumping their version counters,
@@ -365,7 +372,10 @@ class Vid2VidTrainer:
             L["F_Warp"] = masked_l1(resample(real_B_prev, flow), real_B, conf_ref) * wT
             L["W"] = masked_l1(weight, torch.zeros_like(weight), conf_ref) if o["no_first_img"] else torch.zeros((), device=flow.device)
             L["G_Warp"] = masked_l1(fake_B, resample(fake_B_prev, flow_ref).detach(), conf_ref) * wT
-        L["G_VGG"] = torch.zeros((), device=flow.device)  # VGG19 weights are not available offline (no_vgg)
+        if o["no_vgg"]:
+            L["G_VGG"] = torch.zeros((), device=flow.device)  # VGG19 weights are not available offline (no_vgg)
+        else:   # discriminator.py:132-133, :141-142
+            L["G_VGG"] = (self.vgg_loss(fake_B, real_B) + self.vgg_loss(fake_B_raw, real_B)) * o["lambda_feat"]
         # The reference calls compute_loss_D twice (final and raw image, discriminator.py:125-131) and each call
         # evaluates netD on the same real pair with the same weights: identical activations, so it is
         # evaluated once here and counted twice (BatchNorm running statistics advance twice as well;
