@@ -76,15 +76,21 @@ __device__ __forceinline__ s16x4 lds_tr(const unsigned char *p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)p);
 }
 
-template <int DT>
-__global__ void __launch_bounds__(256, 2)
+// SPLIT = 1: 512 threads, waves 0..3 multiply and waves 4..7 only stage (as in conv_wgrad3x3_kernel): the eight LDS-DMA
+// issues of a K-step and their gather arithmetic leave the multiplying waves' instruction streams.  Measured on
+// 1024x1024x3x3 @32x64: 119.9 -> 102.4 us; training window 42.6 -> 42.2 ms.  Default (IR2RGB_WGRAD_SPLIT=0: one role).
+template <int DT, int SPLIT>
+__global__ void __launch_bounds__(SPLIT ? 512 : 256, 2)
 conv_wgrad_kernel(const uint16_t *__restrict__ U, const uint16_t *__restrict__ V, float *__restrict__ D,
                   const WgradGeom g) {
     constexpr int STAGE = 2 * 64 * 256;  // U tile + V tile, 64 pixel rows x 256 B each
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid0 = threadIdx.x, lane = tid0 & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    const bool loader = SPLIT && wave8 >= 4;
+    const int wave = wave8 & 3;            // role-local wave index
+    const int tid = tid0 & 255;            // role-local thread index
     const int nta = (g.Ca + 127) >> 7, ntb = (g.Cb + 127) >> 7;
     // XCD-aware bijective remap (blocks b, b+8, ... share an L2): each XCD gets a contiguous run of
     // (split, tap, tile_a, tile_b) ids, i.e. few distinct U / V panels per private L2.
@@ -189,12 +195,28 @@ conv_wgrad_kernel(const uint16_t *__restrict__ U, const uint16_t *__restrict__ V
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    issue(kbeg, 0);
+    if constexpr (SPLIT) {
+        if (loader) {
+            issue(kbeg, 0);
+            int lb = 0;
+            for (int ks = kbeg; ks < kend; ++ks) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // step ks has landed
+                __builtin_amdgcn_s_barrier();                         // ... and step ks-1 has been consumed
+                if (ks + 1 < kend) issue(ks + 1, lb ^ 1);
+                lb ^= 1;
+            }
+            return;
+        }
+    } else {
+        issue(kbeg, 0);
+    }
     int buf = 0;
     for (int ks = kbeg; ks < kend; ++ks) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (!SPLIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (ks + 1 < kend) issue(ks + 1, buf ^ 1);
+        if constexpr (!SPLIT) {
+            if (ks + 1 < kend) issue(ks + 1, buf ^ 1);
+        }
         const unsigned char *tile = smem + buf * STAGE;
         const unsigned char *pa[4], *pb[4];
 #pragma unroll
@@ -603,8 +625,15 @@ extern "C" int ir2rgb_conv2d_wgrad(const ir2rgb_conv_desc *d, const void *x, con
     }
     const uint16_t *U = (const uint16_t *)(d->transposed ? x : gy), *V = (const uint16_t *)(d->transposed ? gy : x);
     const unsigned grid = (unsigned)((long)g.ksplit * ntaps * ((g.Ca + 127) / 128) * ((g.Cb + 127) / 128));
-    if (d->dtype == IR2RGB_BF16) conv_wgrad_kernel<IR2RGB_BF16><<<grid, 256, 0, s>>>(U, V, workspace, g);
-    else conv_wgrad_kernel<IR2RGB_F16><<<grid, 256, 0, s>>>(U, V, workspace, g);
+    static int split = -1;
+    if (split < 0) { const char *e = getenv("IR2RGB_WGRAD_SPLIT"); split = e ? atoi(e) : 1; }
+    if (split) {
+        if (d->dtype == IR2RGB_BF16) conv_wgrad_kernel<IR2RGB_BF16, 1><<<grid, 512, 0, s>>>(U, V, workspace, g);
+        else conv_wgrad_kernel<IR2RGB_F16, 1><<<grid, 512, 0, s>>>(U, V, workspace, g);
+    } else {
+        if (d->dtype == IR2RGB_BF16) conv_wgrad_kernel<IR2RGB_BF16, 0><<<grid, 256, 0, s>>>(U, V, workspace, g);
+        else conv_wgrad_kernel<IR2RGB_F16, 0><<<grid, 256, 0, s>>>(U, V, workspace, g);
+    }
     wgrad_finish_kernel<<<stream_grid(elems, 256), 256, 0, s>>>(workspace, dw, g.Ca, g.Cb, ntaps, g.ksplit, elems);
     return ir2rgb_launch_status();
 }
