@@ -206,6 +206,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(usable_cpus())
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()   # rank 0 ran the extra forward-only measurement: leave the job together
         dist.destroy_process_group()
 
 
