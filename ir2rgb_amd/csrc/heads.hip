@@ -5,25 +5,42 @@
 //     soft-mask blend (networks.py:89-100, :207-209), one lane per pixel.
 #include "common.h"
 
+// One block = an 8-row x 16-column pixel tile: the (8 + KH - 1) x 16 pixel records it needs (Cout*KH contiguous
+// floats each, reflection resolved at load time) are staged in LDS with coalesced reads -- one lane per pixel reading
+// its own 256-byte record column by column touched 16 times more cache lines per instruction -- then every thread
+// sums KH taps for three (pixel, cout) outputs and stores 16 consecutive x per (cout, row).
+#define HF_TH 8
+#define HF_TW 16
 __global__ void __launch_bounds__(256)
 head_finish_kernel(const float *__restrict__ T, const float *__restrict__ bias, float *__restrict__ out, int H, int W,
-                   int Cout, int KH, int CT, int pad, unsigned acts, float mul, long total) {
+                   int Cout, int KH, int CT, int pad, unsigned acts, float mul, int tiles_x, int tiles_y) {
+    extern __shared__ float rec[];                       // [(HF_TH + KH - 1)][HF_TW][CU + 1]
+    const int CU = Cout * KH, pitch = CU + 1;            // used channels per record (+1: odd pitch, no bank conflicts)
+    const int bx = blockIdx.x % tiles_x, by = (blockIdx.x / tiles_x) % tiles_y;
+    const long n = blockIdx.x / (tiles_x * tiles_y);
+    const int x0 = bx * HF_TW, y0 = by * HF_TH;
+    const int rows = HF_TH + KH - 1;
     const long hw = (long)H * W;
-    for (long g = blockIdx.x * (long)blockDim.x + threadIdx.x; g < total; g += (long)gridDim.x * blockDim.x) {
-        long n = g / hw, p = g - n * hw;
-        int y = (int)(p / W), x = (int)(p - (long)y * W);
-        for (int co = 0; co < Cout; ++co) {
-            float acc = bias ? bias[co] : 0.f;
-            for (int ky = 0; ky < KH; ++ky) {
-                int iy = y + ky - pad;
-                iy = iy < 0 ? -iy : iy;
-                iy = iy >= H ? 2 * H - 2 - iy : iy;
-                acc += T[((n * H + iy) * (long)W + x) * CT + co * KH + ky];
-            }
-            unsigned a = (acts >> (4 * co)) & 15u;
-            float v = a == 1 ? tanhf(acc) : (a == 2 ? 1.f / (1.f + expf(-acc)) : acc * mul);
-            out[(n * Cout + co) * hw + p] = v;
-        }
+    for (int i = threadIdx.x; i < rows * HF_TW * CU; i += 256) {
+        const int k = i % CU, pc = (i / CU) % HF_TW, pr = i / (CU * HF_TW);
+        int iy = y0 + pr - pad;
+        iy = iy < 0 ? -iy : iy;
+        iy = iy >= H ? 2 * H - 2 - iy : iy;
+        const int x = x0 + pc;
+        float v = 0.f;
+        if (x < W && iy >= 0 && iy < H) v = T[((n * H + iy) * (long)W + x) * CT + k];
+        rec[(pr * HF_TW + pc) * pitch + k] = v;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < HF_TH * HF_TW * Cout; o += 256) {
+        const int tx = o % HF_TW, ty = (o / HF_TW) % HF_TH, co = o / (HF_TW * HF_TH);
+        const int y = y0 + ty, x = x0 + tx;
+        if (y >= H || x >= W) continue;
+        float acc = bias ? bias[co] : 0.f;
+        for (int ky = 0; ky < KH; ++ky) acc += rec[((ty + ky) * HF_TW + tx) * pitch + co * KH + ky];
+        const unsigned a = (acts >> (4 * co)) & 15u;
+        const float v = a == 1 ? tanhf(acc) : (a == 2 ? 1.f / (1.f + expf(-acc)) : acc * mul);
+        out[(n * Cout + co) * hw + (long)y * W + x] = v;
     }
 }
 
@@ -85,7 +102,20 @@ head_finish_bwd_kernel(const float *__restrict__ gout, const float *__restrict__
     for (long g = blockIdx.x * (long)blockDim.x + threadIdx.x; g < total; g += (long)gridDim.x * blockDim.x) {
         long n = g / hw, p = g - n * hw;
         int yp = (int)(p / W), x = (int)(p - (long)yp * W);
-        uint16_t *dst = dT + g * CT;
+        // the CT halfs of this pixel leave as 16-byte stores (CT % 8 == 0): channels are produced in order
+        uint4 *dst = reinterpret_cast<uint4 *>(dT + g * CT);
+        uint32_t pk[4] = {0, 0, 0, 0};
+        int c = 0;
+        auto put = [&](float v) {
+            uint16_t h;
+            if (DT == IR2RGB_BF16) { __bf16 b = (__bf16)v; h = __builtin_bit_cast(uint16_t, b); }
+            else { _Float16 b = (_Float16)v; h = __builtin_bit_cast(uint16_t, b); }
+            pk[(c & 7) >> 1] |= (uint32_t)h << (16 * (c & 1));
+            if ((++c & 7) == 0) {
+                dst[(c >> 3) - 1] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                pk[0] = pk[1] = pk[2] = pk[3] = 0;
+            }
+        };
         for (int co = 0; co < Cout; ++co) {
             const unsigned a = (acts >> (4 * co)) & 15u;
             const float *go = gout + (n * Cout + co) * hw, *oo = out + (n * Cout + co) * hw;
@@ -102,14 +132,10 @@ head_finish_bwd_kernel(const float *__restrict__ gout, const float *__restrict__
                 if (y >= 0 && y < H) acc += dpre(y);
                 if (yp >= 1) { t = -yp; y = t - ky + pad; if (y >= 0 && y < H && t >= -pad) acc += dpre(y); }
                 if (yp <= H - 2) { t = 2 * H - 2 - yp; y = t - ky + pad; if (y >= 0 && y < H && t <= H - 1 + pad) acc += dpre(y); }
-                float v = acc;
-                uint16_t h;
-                if (DT == IR2RGB_BF16) { __bf16 b = (__bf16)v; h = __builtin_bit_cast(uint16_t, b); }
-                else { _Float16 b = (_Float16)v; h = __builtin_bit_cast(uint16_t, b); }
-                dst[co * KH + ky] = h;
+                put(acc);
             }
         }
-        for (int c = Cout * KH; c < CT; ++c) dst[c] = 0;
+        while (c < CT) put(0.f);
     }
     // block reduction of the bias sums -> one atomic per block per channel
     __shared__ float red[8][256];
@@ -173,10 +199,15 @@ extern "C" int ir2rgb_head_finish(const float *T, const float *bias, float *out,
                                   int CT, int pad_h, unsigned acts, float mul, void *stream) {
     if (N < 0 || H < 1 || W < 1 || Cout < 1 || Cout > 8 || KH < 1 || CT < Cout * KH || pad_h < 0 || pad_h >= H)
         return IR2RGB_EINVAL;
-    long total = (long)N * H * W;
-    if (total == 0) return IR2RGB_OK;
-    head_finish_kernel<<<stream_grid(total, 256), 256, 0, as_stream(stream)>>>(T, bias, out, H, W, Cout, KH, CT, pad_h,
-                                                                               acts, mul, total);
+    if ((long)N * H * W == 0) return IR2RGB_OK;
+    if (KH > 16) return IR2RGB_ENOSUP;
+    const int tiles_x = (W + HF_TW - 1) / HF_TW, tiles_y = (H + HF_TH - 1) / HF_TH;
+    const long blocks = (long)N * tiles_x * tiles_y;
+    if (blocks > 0x7fffffffL) return IR2RGB_EINVAL;
+    const size_t lds = (size_t)(HF_TH + KH - 1) * HF_TW * (Cout * KH + 1) * sizeof(float);   // <= 23 x 16 x 129 x 4 = 190 KB in theory
+    if (lds > 64 * 1024) return IR2RGB_ENOSUP;                                              // 7x7 heads, Cout <= 8: 51 KB
+    head_finish_kernel<<<(unsigned)blocks, 256, lds, as_stream(stream)>>>(T, bias, out, H, W, Cout, KH, CT, pad_h, acts, mul,
+                                                                          tiles_x, tiles_y);
     return ir2rgb_launch_status();
 }
 
@@ -193,8 +224,9 @@ extern "C" int ir2rgb_warp_blend_fwd(const float *raw, const float *prev, const 
 extern "C" int ir2rgb_head_finish_bwd(const float *gout, const float *out, void *dT, float *dbias, int N, int H, int W,
                                       int Cout, int KH, int CT, int pad_h, unsigned acts, float mul, int dtype,
                                       void *stream) {
-    if (N < 0 || H < 2 || W < 1 || Cout < 1 || Cout > 8 || KH < 1 || CT < Cout * KH || pad_h < 0 || pad_h >= H)
+    if (N < 0 || H < 2 || W < 1 || Cout < 1 || Cout > 8 || KH < 1 || CT < Cout * KH || (CT & 7) || pad_h < 0 || pad_h >= H)
         return IR2RGB_EINVAL;
+    if (((uintptr_t)dT & 15) != 0) return IR2RGB_EALIGN;
     if (dtype != IR2RGB_BF16 && dtype != IR2RGB_F16) return IR2RGB_ENOSUP;
     long total = (long)N * H * W;
     hipStream_t s = as_stream(stream);
