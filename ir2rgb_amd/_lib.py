@@ -35,6 +35,14 @@ class LossItem(ctypes.Structure):
 
 _pitem = ctypes.POINTER(LossItem)
 
+
+class PackJob(ctypes.Structure):
+    """ir2rgb_pack_job of include/ir2rgb_hip.h."""
+    _fields_ = [("desc", ConvDesc), ("w", c_void_p), ("wpacked", c_void_p), ("adjoint", c_int), ("reserved", c_int)]
+
+
+_pjob = ctypes.POINTER(PackJob)
+
 # name -> (restype, argtypes)
 PROTOTYPES = {
     "ir2rgb_version": (ctypes.c_char_p, []),
@@ -50,6 +58,9 @@ PROTOTYPES = {
     "ir2rgb_conv2d_stats_rows": (c_int, [_pdesc]),
     "ir2rgb_conv2d_pack_weight": (c_int, [_pdesc, P, P, P]),
     "ir2rgb_conv2d_pack_weight_adjoint": (c_int, [_pdesc, P, P, P]),
+    "ir2rgb_conv2d_pack_batch_entry_bytes": (c_int, []),
+    "ir2rgb_conv2d_pack_batch_build": (c_int, [_pjob, c_int, P, c_int, _pint]),
+    "ir2rgb_conv2d_pack_batch_run": (c_int, [P, c_int, c_int, c_int, P]),
     "ir2rgb_conv2d_fwd": (c_int, [_pdesc, P, P, P, P, P, P]),
     "ir2rgb_conv2d_kernel_name": (ctypes.c_char_p, [_pdesc]),
     "ir2rgb_bn_finalize": (c_int, [P, c_int, c_int, c_long, P, P, P, P, c_float, c_float, P, P, P, P, c_int, P]),

@@ -63,6 +63,38 @@ def empty_nhwc(n, c, h, w, dtype, device):
     return torch.empty((n, c, h, w), dtype=dtype, device=device, memory_format=torch.channels_last)
 
 
+class PackBatch:
+    """Every (descriptor, fp32 weight, packed buffer, adjoint) job of a network refreshed by one launch
+    (``run``), in place.  The device table is built once; it holds raw pointers, so the weight and
+    packed tensors are kept alive here and must not be reallocated."""
+
+    def __init__(self, jobs):
+        lib = _lib.lib()
+        self.keep = [(w, p) for _, w, p, _ in jobs]
+        arr = (_lib.PackJob * len(jobs))()
+        for j, (desc, w, packed, adjoint) in enumerate(jobs):
+            _lib.require_device(w, dtype=torch.float32)
+            _lib.require_device(packed)
+            arr[j].desc, arr[j].w, arr[j].wpacked, arr[j].adjoint = desc, w.data_ptr(), packed.data_ptr(), int(bool(adjoint))
+        self.dtype = jobs[0][0].dtype
+        self.device = jobs[0][1].device
+        esz = lib.ir2rgb_conv2d_pack_batch_entry_bytes()
+        host = torch.zeros(4 * len(jobs) * esz, dtype=torch.uint8)
+        nblocks = ctypes.c_int(0)
+        n = lib.ir2rgb_conv2d_pack_batch_build(arr, len(jobs), ctypes.c_void_p(host.data_ptr()), 4 * len(jobs),
+                                               ctypes.byref(nblocks))
+        if n < 0:
+            _lib.check(int(n), "conv2d_pack_batch_build")
+        self.nentries, self.nblocks = int(n), int(nblocks.value)
+        self.table = host[:self.nentries * esz].to(self.device)
+
+    def run(self):
+        with _lib.on_device(self.table):
+            rc = _lib.lib().ir2rgb_conv2d_pack_batch_run(_p(self.table), self.nentries, self.nblocks, self.dtype,
+                                                         _lib.current_stream(self.table))
+        _lib.check(rc, "conv2d_pack_batch_run")
+
+
 def pack_weight(desc, weight, adjoint=False):
     """weight: fp32 torch layout ([Cout,Cin,kh,kw], or [Cin,Cout,kh,kw] for transposed).  adjoint=True:
     ``desc`` is the data-gradient convolution of a stride-1 Conv2d and ``weight`` its forward weight."""

@@ -29,6 +29,7 @@
 //
 // Algorithmic flops = 2 * pixels * Cout * ntaps * Cin; roofline bound: MFMA.
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #include <utility>
 
@@ -506,10 +507,10 @@ struct PackGeom {
 };
 
 template <int DT>
-__global__ void __launch_bounds__(256)
-pack_weight_kernel(const float *__restrict__ w, uint16_t *__restrict__ wp, const PackGeom g, long total) {
+__device__ __forceinline__ void pack_weight_body(const float *__restrict__ w, uint16_t *__restrict__ wp, const PackGeom &g,
+                                                 long total, long first, long stride) {
     const int kchunks = g.Cin / 64;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    for (long i = first; i < total; i += stride) {
         long r = i;
         int c64 = (int)(r & 63); r >>= 6;
         int tap = (int)(r % g.ntaps); r /= g.ntaps;
@@ -523,6 +524,12 @@ pack_weight_kernel(const float *__restrict__ w, uint16_t *__restrict__ wp, const
     }
 }
 
+template <int DT>
+__global__ void __launch_bounds__(256)
+pack_weight_kernel(const float *__restrict__ w, uint16_t *__restrict__ wp, const PackGeom g, long total) {
+    pack_weight_body<DT>(w, wp, g, total, blockIdx.x * (long)blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
+
 // Tiled packing of a plain Conv2d weight [Cout][Cin][T] (T = kh*kw <= 9 taps in row-major order, one
 // class).  A block stages a TCO x TCI x T tile through LDS so that both the fp32 reads (TCI*T contiguous
 // floats per co) and the half writes (64 contiguous halfs per (row, tap)) are coalesced; the tile is
@@ -533,13 +540,14 @@ pack_weight_kernel(const float *__restrict__ w, uint16_t *__restrict__ wp, const
 //   ADJ = 1 (64 co x 16 ci):  Wp[ci][co/64][T-1-t][co%64]   = w[co][ci][t]   (data-gradient operand:
 //             roles of the channel axes swapped, taps flipped)
 #define PACK_MAX_T 9
+#define PACK_TILE_HALFS (64 * (16 * PACK_MAX_T + 4))     // the larger of the two tile shapes
 template <int DT, int ADJ>
-__global__ void __launch_bounds__(256)
-pack_tile_kernel(const float *__restrict__ w, uint16_t *__restrict__ wp, int Cout, int Cin, int T) {
+__device__ __forceinline__ void pack_tile_body(const float *__restrict__ w, uint16_t *__restrict__ wp, int Cout, int Cin,
+                                               int T, int bx, int by, uint16_t *tile) {
     constexpr int TCO = ADJ ? 64 : 16, TCI = ADJ ? 16 : 64;
-    __shared__ uint16_t tile[TCO * (TCI * PACK_MAX_T + 4)];
+    static_assert(TCO * (TCI * PACK_MAX_T + 4) <= PACK_TILE_HALFS, "tile buffer");
     const int row = TCI * T + 4;                          // halfs per co row (+4: spreads the banks)
-    const int co0 = blockIdx.y * TCO, ci0 = blockIdx.x * TCI;
+    const int co0 = by * TCO, ci0 = bx * TCI;
     const int q_per_row = TCI * T / 4;                    // float4 per co row
     for (int i = threadIdx.x; i < TCO * q_per_row; i += 256) {
         const int co_l = i / q_per_row, q = i - co_l * q_per_row;
@@ -564,7 +572,7 @@ pack_tile_kernel(const float *__restrict__ w, uint16_t *__restrict__ wp, int Cou
                 const uint32_t hi = tile[(o8 * 8 + 2 * j + 1) * row + r * T + t];
                 o[j] = lo | (hi << 16);
             }
-            const long dst = ((((long)(ci0 + r) * kch + blockIdx.y) * T + (T - 1 - t)) * 64 + o8 * 8);
+            const long dst = ((((long)(ci0 + r) * kch + by) * T + (T - 1 - t)) * 64 + o8 * 8);
             *reinterpret_cast<uint4 *>(wp + dst) = make_uint4(o[0], o[1], o[2], o[3]);
         }
     } else {
@@ -581,10 +589,54 @@ pack_tile_kernel(const float *__restrict__ w, uint16_t *__restrict__ wp, int Cou
                 const uint32_t hi = tile[r * row + (o8 * 8 + 2 * j + 1) * T + t];
                 o[j] = lo | (hi << 16);
             }
-            const long dst = ((((long)(co0 + r) * kch + blockIdx.x) * T + t) * 64 + o8 * 8);
+            const long dst = ((((long)(co0 + r) * kch + bx) * T + t) * 64 + o8 * 8);
             *reinterpret_cast<uint4 *>(wp + dst) = make_uint4(o[0], o[1], o[2], o[3]);
         }
     }
+}
+
+template <int DT, int ADJ>
+__global__ void __launch_bounds__(256)
+pack_tile_kernel(const float *__restrict__ w, uint16_t *__restrict__ wp, int Cout, int Cin, int T) {
+    __shared__ uint16_t tile[PACK_TILE_HALFS];
+    pack_tile_body<DT, ADJ>(w, wp, Cout, Cin, T, blockIdx.x, blockIdx.y, tile);
+}
+
+// Batched packing: every weight of a network in ONE launch.  After an optimizer step ~280 packed copies
+// (forward and data-gradient operands) are stale; most are small and their individual launches cost
+// more than their bytes.  The table (device memory, built once by ir2rgb_conv2d_pack_batch_build) lists
+// one entry per (weight, class); a block finds its entry by its index among the entries' block ranges.
+struct PackEntry {
+    const float *w;
+    uint16_t *wp;
+    long total;                 // kind 0: elements of this class
+    int kind;                   // 0 = generic gather, 1 = tile forward, 2 = tile adjoint
+    int first_block, nblocks;
+    int Cout, Cin, T, gx;       // kinds 1/2: source dims, taps, blocks along ci
+    PackGeom g;                 // kind 0
+};
+
+template <int DT>
+__global__ void __launch_bounds__(256)
+pack_batch_kernel(const PackEntry *__restrict__ E, int n) {
+    __shared__ uint16_t tile[PACK_TILE_HALFS];
+    __shared__ int which;
+    __shared__ PackEntry e;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int f = E[i].first_block;
+        if ((int)blockIdx.x >= f && (int)blockIdx.x < f + E[i].nblocks) which = i;
+    }
+    __syncthreads();
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(E + which);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(&e);
+        for (int i = threadIdx.x; i < (int)(sizeof(PackEntry) / 4); i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lb = blockIdx.x - e.first_block;
+    if (e.kind == 0) pack_weight_body<DT>(e.w, e.wp, e.g, e.total, lb * 256L + threadIdx.x, e.nblocks * 256L);
+    else if (e.kind == 1) pack_tile_body<DT, 0>(e.w, e.wp, e.Cout, e.Cin, e.T, lb % e.gx, lb / e.gx, tile);
+    else pack_tile_body<DT, 1>(e.w, e.wp, e.Cout, e.Cin, e.T, lb % e.gx, lb / e.gx, tile);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -834,6 +886,77 @@ static int pack_impl(const ir2rgb_conv_desc *d, const float *w, void *wpacked, v
 
 extern "C" int ir2rgb_conv2d_pack_weight(const ir2rgb_conv_desc *d, const float *w, void *wpacked, void *stream) {
     return pack_impl(d, w, wpacked, stream, false);
+}
+
+// The entries pack_impl's launches correspond to (same decisions, same kernels' bodies).
+static int pack_entries(const ir2rgb_conv_desc *d, const float *w, void *wpacked, bool adjoint, PackEntry *out) {
+    ClassPlan plans[4];
+    int n = make_plan(d, plans);
+    if (n < 0) return n;
+    if (adjoint && d->transposed) return IR2RGB_ENOSUP;
+    if (!w || !wpacked) return IR2RGB_EINVAL;
+    const PackGeom &pg = plans[0].pack;
+    const int T = d->kh * d->kw;
+    bool natural = n == 1 && !d->transposed && !pg.transposed && !pg.flip && pg.ntaps == T && T <= PACK_MAX_T;
+    for (int t = 0; natural && t < T; ++t) natural = pg.ky[t] == t / d->kw && pg.kx[t] == t % d->kw;
+    const int srcCout = adjoint ? d->Cin : d->Cout, srcCin = adjoint ? d->Cout : d->Cin;
+    if (natural && srcCin % 64 == 0 && (!adjoint || srcCout % 64 == 0) && (((uintptr_t)w | (uintptr_t)wpacked) & 15) == 0) {
+        const int tco = adjoint ? 64 : 16, tci = adjoint ? 16 : 64;
+        PackEntry &e = out[0];
+        memset(&e, 0, sizeof(e));
+        e.w = w;
+        e.wp = reinterpret_cast<uint16_t *>(wpacked);
+        e.kind = adjoint ? 2 : 1;
+        e.Cout = srcCout; e.Cin = srcCin; e.T = T;
+        e.gx = srcCin / tci;
+        e.nblocks = e.gx * ((srcCout + tco - 1) / tco);
+        return 1;
+    }
+    for (int i = 0; i < n; ++i) {
+        PackEntry &e = out[i];
+        memset(&e, 0, sizeof(e));
+        e.g = plans[i].pack;
+        if (adjoint) { e.g.transposed = 1; e.g.flip = 1; }
+        e.total = (long)d->Cout * d->Cin * plans[i].geom.ntaps;
+        e.w = w;
+        e.wp = reinterpret_cast<uint16_t *>(wpacked) + plans[i].w_offset;
+        e.kind = 0;
+        long nb = (e.total + 2047) / 2048;
+        e.nblocks = (int)(nb < 1 ? 1 : (nb > 128 ? 128 : nb));
+    }
+    return n;
+}
+
+extern "C" int ir2rgb_conv2d_pack_batch_entry_bytes(void) { return (int)sizeof(PackEntry); }
+
+extern "C" int ir2rgb_conv2d_pack_batch_build(const ir2rgb_pack_job *jobs, int njobs, void *table_host, int max_entries,
+                                              int *nblocks) {
+    if (!jobs || njobs < 1 || !table_host || !nblocks) return IR2RGB_EINVAL;
+    PackEntry *E = reinterpret_cast<PackEntry *>(table_host);
+    int n = 0, blocks = 0;
+    for (int j = 0; j < njobs; ++j) {
+        if (jobs[j].desc.dtype != jobs[0].desc.dtype) return IR2RGB_EINVAL;    // one element type per launch
+        PackEntry tmp[4];
+        const int k = pack_entries(&jobs[j].desc, jobs[j].w, jobs[j].wpacked, jobs[j].adjoint != 0, tmp);
+        if (k < 0) return k;
+        if (n + k > max_entries) return IR2RGB_EINVAL;
+        for (int i = 0; i < k; ++i) {
+            tmp[i].first_block = blocks;
+            blocks += tmp[i].nblocks;
+            E[n++] = tmp[i];
+        }
+    }
+    *nblocks = blocks;
+    return n;
+}
+
+extern "C" int ir2rgb_conv2d_pack_batch_run(const void *table_dev, int nentries, int nblocks, int dtype, void *stream) {
+    if (!table_dev || nentries < 1 || nblocks < 1) return IR2RGB_EINVAL;
+    if (dtype != IR2RGB_BF16 && dtype != IR2RGB_F16) return IR2RGB_ENOSUP;
+    const PackEntry *E = reinterpret_cast<const PackEntry *>(table_dev);
+    if (dtype == IR2RGB_BF16) pack_batch_kernel<IR2RGB_BF16><<<nblocks, 256, 0, as_stream(stream)>>>(E, nentries);
+    else pack_batch_kernel<IR2RGB_F16><<<nblocks, 256, 0, as_stream(stream)>>>(E, nentries);
+    return ir2rgb_launch_status();
 }
 
 extern "C" int ir2rgb_conv2d_pack_weight_adjoint(const ir2rgb_conv_desc *d, const float *w, void *wpacked, void *stream) {

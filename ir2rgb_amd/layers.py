@@ -49,8 +49,50 @@ def packed_weight(mod, desc, weight=None, tag="w", adjoint=False):
         if w.dtype != torch.float32 or not w.is_contiguous():
             w = w.float().contiguous()
         packed = C.pack_weight(desc, w, adjoint=adjoint)
-    cache[tag] = (key, packed)
+    # a "plain" entry is packed straight from the parameter's own storage: WeightRepacker can refresh it in place
+    plain = weight is None and w.data_ptr() == src.data_ptr()
+    cache[tag] = (key, packed, C.ConvDesc.from_buffer_copy(desc) if plain else None, bool(adjoint))
     return packed
+
+
+class WeightRepacker:
+    """Refreshes, with ONE launch, every plain packed-weight copy cached under ``modules`` (forward and
+    data-gradient operands) -- call ``run()`` right after the optimizer step that changed the weights.
+    Without it each layer repacks lazily at its next use, ~280 small launches per training window.
+    The packed buffers are overwritten in place, so no autograd graph recorded before the step may be
+    run backward after it (torch itself refuses that for in-place updated parameters).  Entries packed
+    from a rearranged weight (separable heads, padded thin layers) keep their lazy path."""
+
+    def __init__(self, modules):
+        self.modules = [m for root in modules for m in root.modules() if getattr(m, "weight", None) is not None]
+        self.batch, self.sig, self.entries = None, None, []
+
+    def _collect(self):
+        ent = []
+        for m in self.modules:
+            for tag, hit in m.__dict__.get("_ir2rgb_packed", {}).items():
+                if len(hit) == 4 and hit[2] is not None and hit[0][3] == m.weight.data_ptr():
+                    ent.append((m, tag, hit))
+        return ent
+
+    def run(self):
+        ent = self._collect()
+        if not ent:
+            return 0
+        sig = tuple((id(m), tag, hit[1].data_ptr(), hit[0][3], hit[0][1]) for m, tag, hit in ent)
+        if sig != self.sig:      # first call, or a layer packed a new buffer since (new shape / first backward)
+            by_dtype = {}
+            for e in ent:
+                by_dtype.setdefault(e[2][0][1], []).append(e)
+            self.batch = [C.PackBatch([(hit[2], m.weight.detach(), hit[1], hit[3]) for m, tag, hit in es])
+                          for es in by_dtype.values()]
+            self.sig = sig
+        for b in self.batch:
+            b.run()
+        for m, tag, hit in ent:
+            k = hit[0]
+            m._ir2rgb_packed[tag] = ((k[0], k[1], m.weight._version) + tuple(k[3:]),) + tuple(hit[1:])
+        return len(ent)
 
 
 # ---------------------------------------------------------------------------------------------

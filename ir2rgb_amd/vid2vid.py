@@ -36,6 +36,7 @@ DEFAULTS = dict(  # options/base_options.py, options/train_options.py (SURVEY se
     shared_fake_forward=True,   # one netD forward on generated frames serves the D and the G loss (autograd.backward_flags)
     fused_adam=True,     # one-launch HIP Adam (ir2rgb_amd.optim); False = torch.optim.Adam(foreach=True)
     fused_losses=True,   # grouped HIP loss kernels (ir2rgb_amd.losses); False = the same terms through torch ops
+    batched_repack=True,  # all packed weight copies refreshed by one launch after the optimizer steps (layers.WeightRepacker)
 )
 
 
@@ -266,6 +267,7 @@ class Vid2VidTrainer:
         self.optimizer_G = make(self.grads_G.params)
         self.optimizer_D = make(self.grads_D.params)
         self.optimizer_D_T = [make(g.params) for g in self.grads_DT]
+        self.repacker = layers.WeightRepacker(list(self.netG) + [self.netD] + list(self.netD_T)) if o["batched_repack"] else None
         self.reset_sequence()
 
     # ------------------------------------------------------------------ per-sequence state
@@ -508,6 +510,8 @@ class Vid2VidTrainer:
         for s in range(len(loss_D_T)):
             self.grads_DT[s].wait()
             self.optimizer_D_T[s].step()
+        if self.repacker is not None:
+            self.repacker.run()          # every packed forward / data-gradient weight copy, one launch
         out = {"G": loss_G.detach(), "D": loss_D.detach()}
         out.update({f"D_T{s}": l.detach() for s, l in enumerate(loss_D_T)})
         return out

@@ -172,7 +172,7 @@ def test_optimizer_step_reaches_the_packed_weights():
     A, B = V.synthetic_sequence(5, 64, 128, 7, dev)
     res = []
     for fused in (True, False):
-        tr = V.Vid2VidTrainer(dev, seed=0, first_layer_gen_filters=64, gen_blocks=2, fused_adam=fused)
+        tr = V.Vid2VidTrainer(dev, seed=0, first_layer_gen_filters=64, gen_blocks=2, fused_adam=fused, batched_repack=False)
         first = {k: v.item() for k, v in tr.train_window(A[:, 0:3], B[:, 0:3]).items()}
         second = {k: v.item() for k, v in tr.train_window(A[:, 1:4], B[:, 1:4]).items()}
         res.append(second)
@@ -180,13 +180,43 @@ def test_optimizer_step_reaches_the_packed_weights():
         n_checked = 0
         for net in tr.netG + [tr.netD]:
             for m in net.modules():
-                for tag, (key, _) in getattr(m, "_ir2rgb_packed", {}).items():
+                for tag, hit in getattr(m, "_ir2rgb_packed", {}).items():
+                    key = hit[0]
                     if tag in ("w", "xexp"):
                         assert m.weight._version > key[2], "optimizer step did not invalidate the packed weight"
                         n_checked += 1
         assert n_checked > 20
     for k in res[0]:
         assert abs(res[0][k] - res[1][k]) <= 5e-3 * abs(res[1][k]), (k, res[0][k], res[1][k])
+
+
+def test_batched_repack_equals_lazy_repack():
+    """layers.WeightRepacker (one launch refreshing every packed weight copy in place after the optimizer
+    steps) against the lazy per-layer repack: bit-identical losses over three windows, every refreshed
+    buffer bit-identical to a fresh individual pack of the current parameter, and the cache keys current."""
+    from ir2rgb_amd import conv as C
+    from ir2rgb_amd import vid2vid as V
+    dev = _dev()
+    A, B = V.synthetic_sequence(6, 64, 128, 7, dev)
+    res = []
+    for batched in (True, False):
+        tr = V.Vid2VidTrainer(dev, seed=0, first_layer_gen_filters=64, gen_blocks=2, batched_repack=batched)
+        res.append([{k: v.item() for k, v in tr.train_window(A[:, w:w + 3], B[:, w:w + 3]).items()} for w in range(3)])
+        if not batched:
+            continue
+        n_plain, kinds = 0, set()
+        for net in tr.netG + [tr.netD] + tr.netD_T:
+            for m in net.modules():
+                for tag, hit in getattr(m, "_ir2rgb_packed", {}).items():
+                    if len(hit) == 4 and hit[2] is not None:
+                        assert hit[0][2] == m.weight._version, (type(m).__name__, tag)
+                        fresh = C.pack_weight(hit[2], m.weight.detach(), adjoint=hit[3])
+                        assert torch.equal(fresh.view(torch.int16), hit[1].view(torch.int16)), (type(m).__name__, tag)
+                        n_plain += 1
+                        kinds.add((tag, hit[3], hit[2].transposed, hit[2].kh, hit[2].stride_h))
+        assert n_plain > 40 and len(kinds) >= 6, (n_plain, kinds)
+        assert tr.repacker.batch is not None and sum(b.nentries for b in tr.repacker.batch) >= n_plain
+    assert res[0] == res[1]
 
 
 def test_shared_discriminator_forward_changes_nothing():
