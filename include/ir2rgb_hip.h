@@ -245,6 +245,13 @@ int ir2rgb_bn_bwd(const void *gz, const void *y, const float *scale, const float
                   const float *invstd, void *gy, float *dgamma, float *dbeta, float *partial, long npix, int C,
                   int act, int dtype, void *stream);
 
+/* Gradient of a thin fp32 convolution output (the 1-channel PatchGAN logits, NLayerDiscriminator's last
+ * layer, networks.py:676-677) prepared for the MFMA kernels: gz [N,Cout,H,W] fp32, Cout <= 8 ->
+ * g64 [N,H,W,64] and g8 [N,H,W,8] NHWC half (channels >= Cout zero; data- / weight-gradient operands) and
+ * dbias[Cout] = sum over N,H,W of gz (deterministic). */
+int ir2rgb_thin_grad_expand(const float *gz, void *g64, void *g8, float *dbias, int N, int Cout, int H, int W,
+                            int dtype, void *stream);
+
 /* Adjoint of nn.ReflectionPad2d: dxpad [N,H+2*pad_h,W+2*pad_w,C] -> dx [N,H,W,C] (NHWC half). */
 int ir2rgb_fold_reflect(const void *dxpad, void *dx, int N, int H, int W, int C, int pad_h, int pad_w, int dtype,
                         void *stream);

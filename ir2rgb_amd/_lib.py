@@ -75,6 +75,7 @@ PROTOTYPES = {
     "ir2rgb_warp_blend_fwd": (c_int, [P] * 6 + [c_int] * 4 + [P]),
     "ir2rgb_bn_bwd_blocks": (c_int, [c_long, c_int]),
     "ir2rgb_bn_bwd": (c_int, [P] * 10 + [c_long, c_int, c_int, c_int, P]),
+    "ir2rgb_thin_grad_expand": (c_int, [P, P, P, P] + [c_int] * 5 + [P]),
     "ir2rgb_fold_reflect": (c_int, [P, P] + [c_int] * 7 + [P]),
     "ir2rgb_head_finish_bwd": (c_int, [P, P, P, P] + [c_int] * 7 + [ctypes.c_uint, c_float, c_int, P]),
     "ir2rgb_warp_blend_bwd": (c_int, [P] * 8 + [c_int] * 4 + [P]),

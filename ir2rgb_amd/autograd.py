@@ -59,6 +59,21 @@ def bn_bwd(gz, y, scale, shift, mean, invstd, act):
     return gy, dgamma, dbeta
 
 
+def thin_grad_expand(gz, dtype):
+    """fp32 gradient [N,Cout<=8,H,W] of a thin output -> (g64, g8, dbias): 64- and 8-channel zero-padded
+    channels_last half copies and the per-channel sum, one launch."""
+    gz = gz.float().contiguous()
+    n, cout, h, w = gz.shape
+    g64 = C.empty_nhwc(n, 64, h, w, dtype, gz.device)
+    g8 = C.empty_nhwc(n, 8, h, w, dtype, gz.device)
+    dbias = torch.empty(cout, dtype=torch.float32, device=gz.device)
+    with _lib.on_device(gz):
+        rc = _lib.lib().ir2rgb_thin_grad_expand(_p(gz), _p(g64), _p(g8), _p(dbias), n, cout, h, w, _DT[dtype],
+                                                _lib.current_stream(gz))
+    _lib.check(rc, "thin_grad_expand")
+    return g64, g8, dbias
+
+
 def fold_reflect(dxpad, pad_h, pad_w=None):
     pad_w = pad_h if pad_w is None else pad_w
     n, ch, hp, wp = dxpad.shape
@@ -315,11 +330,7 @@ class ConvStageFn(Function):
         if spec.get("out_f32", False):
             # thin fp32 output (PatchGAN logits): pad the gradient to 64 channels for the MFMA adjoint
             cout = y.shape[1]
-            dbias = gz.float().sum((0, 2, 3))
-            gy_thin = gz.to(hdt).contiguous(memory_format=torch.channels_last)
-            gy = torch.zeros((gz.shape[0], 64, gz.shape[2], gz.shape[3]), dtype=hdt, device=gz.device).contiguous(
-                memory_format=torch.channels_last)
-            gy[:, :cout] = gy_thin
+            gy, gy_thin, dbias = thin_grad_expand(gz, hdt)      # 64-channel / 8-channel zero-padded halves, sum
             pad_fn = lambda w: torch.cat([w, w.new_zeros((64 - w.shape[0],) + tuple(w.shape[1:]))], 0)  # noqa: E731
             dgamma = dbeta = None
         elif ctx.has_bn:
@@ -363,7 +374,12 @@ class ConvStageFn(Function):
                     return gwe.permute(0, 1, 3, 2).contiguous()
                 dw = wgrad_overlapped(conv, first_wgrad, xin, gy)
             else:
-                dw = wgrad_overlapped(conv, lambda: conv_wgrad(xin, gy, tuple(conv.weight.shape), spec), xin, gy)
+                if spec.get("out_f32", False):   # gy holds 8 zero-padded channels: the extra rows are dropped
+                    wsh = (8,) + tuple(conv.weight.shape[1:])
+                    dw = wgrad_overlapped(conv, lambda: conv_wgrad(xin, gy, wsh, spec)[:conv.out_channels].contiguous(),
+                                          xin, gy)
+                else:
+                    dw = wgrad_overlapped(conv, lambda: conv_wgrad(xin, gy, tuple(conv.weight.shape), spec), xin, gy)
         r1 = gz if ctx.has_res[0] else None
         r2 = gz if ctx.has_res[1] else None
         return dx, dw, (dbias if ctx.needs_input_grad[2] else None), dgamma, dbeta, r1, r2, None, None, None

@@ -256,6 +256,48 @@ xexpand_bwd_kernel(const uint16_t *__restrict__ dxe, float *__restrict__ din, in
     }
 }
 
+// Gradient of a thin fp32 output (the 1-channel PatchGAN logits, Cout <= 8) prepared for the MFMA kernels in
+// one pass: g64 = the gradient as a 64-channel NHWC half tensor (data-gradient operand, channels >= Cout zero),
+// g8 = the same in 8 channels (weight-gradient operand), dbias[c] = sum of the fp32 gradient.  Eight lanes
+// share a pixel (one 16-byte store each into its 128-byte g64 row); the last Cout blocks reduce one channel
+// each in a fixed order.
+__global__ void __launch_bounds__(256)
+thin_grad_expand_kernel(const float *__restrict__ gz, uint4 *__restrict__ g64, uint4 *__restrict__ g8,
+                        float *__restrict__ dbias, long npix, long hw, int Cout, int dt, int expand_blocks) {
+    if ((int)blockIdx.x >= expand_blocks) {
+        __shared__ float red[256];
+        const int c = blockIdx.x - expand_blocks;
+        float s = 0.f;
+        for (long p = threadIdx.x; p < npix; p += 256) {
+            const long n = p / hw;
+            s += gz[(n * Cout + c) * hw + (p - n * hw)];
+        }
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int w = 128; w >= 1; w >>= 1) {
+            if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) dbias[c] = red[0];
+        return;
+    }
+    const long total = npix * 8;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += expand_blocks * 256L) {
+        const long p = i >> 3;
+        const int o8 = (int)(i & 7);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (o8 == 0) {
+            const long n = p / hw, q = p - n * hw;
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = j < Cout ? gz[(n * Cout + j) * hw + q] : 0.f;
+            v = pack8(f, dt);
+            g8[p] = v;
+        }
+        g64[i] = v;
+    }
+}
+
 // R pixel ranges per 64-channel group: about 512 blocks of 1024 threads in all, at least 128 pixels
 // per range and at most 128 ranges (bn_bwd_finalize_kernel's 8 slices x 16 rows).
 static int bn_bwd_ranges(long npix, int C) {
@@ -315,5 +357,18 @@ extern "C" int ir2rgb_xexpand_bwd(const void *dxe, float *din, int N, int Cin, i
     if (total == 0) return IR2RGB_OK;
     xexpand_bwd_kernel<<<stream_grid(total, 256), 256, 0, as_stream(stream)>>>((const uint16_t *)dxe, din, Cin, H, W, Wout,
                                                                                KW, stride_w, pad_w, pad_mode, total, dtype);
+    return ir2rgb_launch_status();
+}
+
+extern "C" int ir2rgb_thin_grad_expand(const float *gz, void *g64, void *g8, float *dbias, int N, int Cout, int H, int W,
+                                       int dtype, void *stream) {
+    if (N < 0 || Cout < 1 || Cout > 8 || H < 1 || W < 1 || !gz || !g64 || !g8 || !dbias) return IR2RGB_EINVAL;
+    if (dtype != IR2RGB_BF16 && dtype != IR2RGB_F16) return IR2RGB_ENOSUP;
+    if (((uintptr_t)g64 | (uintptr_t)g8) & 15) return IR2RGB_EALIGN;
+    const long npix = (long)N * H * W;
+    if (npix == 0) return IR2RGB_OK;
+    const int eb = stream_grid(npix * 8, 256);
+    thin_grad_expand_kernel<<<eb + Cout, 256, 0, as_stream(stream)>>>(gz, (uint4 *)g64, (uint4 *)g8, dbias, npix,
+                                                                      (long)H * W, Cout, dtype, eb);
     return ir2rgb_launch_status();
 }

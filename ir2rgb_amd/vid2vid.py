@@ -197,14 +197,17 @@ class FlatGrads:
             p.grad = None
 
     def all_reduce_async(self, world):
-        src, dst = [], []
+        src, dst, missing = [], [], []
         for p, v in zip(self.params, self.views):
             if p.grad is None:
-                p.grad = v.zero_()
+                missing.append(v)
+                p.grad = v
             elif world > 1:
                 src.append(p.grad)
                 dst.append(v)
                 p.grad = v
+        if missing:
+            torch._foreach_zero_(missing)      # one multi-tensor launch instead of one fill per parameter
         if world <= 1:
             return
         torch._foreach_copy_(dst, src)

@@ -114,6 +114,27 @@ def test_first_and_last_discriminator_layers_backward(dev, dtype, tol):
     assert not bad, errs
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(1, 1, 35, 67), (3, 1, 67, 131), (2, 3, 5, 9), (1, 8, 4, 4)])
+def test_thin_grad_expand(dev, dtype, shape):
+    """ir2rgb_thin_grad_expand against the torch ops it replaced (cast, zero-padded channel copies, sum):
+    the half copies are bit-exact, the sum agrees to fp32 summation order."""
+    from ir2rgb_amd import autograd as A
+    torch.manual_seed(5)
+    gz = torch.randn(shape, device=dev)
+    g64, g8, dbias = A.thin_grad_expand(gz, dtype)
+    n, c, h, w = shape
+    for got, ch in ((g64, 64), (g8, 8)):
+        assert got.shape == (n, ch, h, w) and got.is_contiguous(memory_format=torch.channels_last)
+        want = torch.zeros((n, ch, h, w), dtype=dtype, device=dev)
+        want[:, :c] = gz.to(dtype)
+        assert torch.equal(got, want)
+    ref = gz.double().sum((0, 2, 3))
+    assert (dbias.double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+    with pytest.raises(ValueError):
+        A.thin_grad_expand(torch.randn(1, 9, 4, 4, device=dev), dtype)
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 1e-2), (torch.bfloat16, 4e-2)])
 def test_generator_first_layer_backward(dev, dtype, tol):
     """ReflectionPad2d(3)+Conv7x7+BN+ReLU on a 9-channel image: weight / BN gradients (no input grad)."""
