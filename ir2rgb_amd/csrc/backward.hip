@@ -41,17 +41,18 @@ __device__ __forceinline__ float act_grad(float g, float pre, int act) {
     return g;
 }
 
-// One block (1024 threads) = one 64-channel group x one pixel range.  partial[r][0][c] = sum g',
+// One block (512 threads) = one 64-channel group x one pixel range.  partial[r][0][c] = sum g',
 // partial[r][1][c] = sum g' * yhat over range r.  Thread t owns channel octet t & 7 of the group
-// and pixel rows (t >> 3) + 128k of the range, four rows in flight: a dependent HBM round trip
+// and pixel rows (t >> 3) + 64k of the range, four rows in flight: a dependent HBM round trip
 // costs ~2 us here, so these small reductions are shaped to need as few of them as possible.
 // (A last-block-finalises variant was measured: the device-scope fences it needs write back the
-// XCD L2s and made this kernel 4x slower than reduce + a separate finalize launch.)
-__global__ void __launch_bounds__(1024)
+// XCD L2s and made this kernel 4x slower than reduce + a separate finalize launch.  With 1024 threads the
+// 128-VGPR cap made the compiler spill 18 registers: scratch costs dispatch latency, ~14 us floor per call.)
+__global__ void __launch_bounds__(512)
 bn_bwd_reduce_kernel(const uint4 *__restrict__ gz, const uint4 *__restrict__ y, const float *__restrict__ scale,
                      const float *__restrict__ shift, const float *__restrict__ mean, const float *__restrict__ invstd,
                      float *__restrict__ partial, long npix, int C, int act, int dt, long pix_per_block) {
-    __shared__ float red[2][16][64];
+    __shared__ float red[2][8][64];
     const int octs = C >> 3, ngroups = C >> 6;
     const int cg = blockIdx.x % ngroups, r = blockIdx.x / ngroups;
     const int oc = threadIdx.x & 7, row = threadIdx.x >> 3, wave = threadIdx.x >> 6;
@@ -68,11 +69,11 @@ bn_bwd_reduce_kernel(const uint4 *__restrict__ gz, const uint4 *__restrict__ y, 
         is[j] = invstd ? invstd[c0 + j] : 1.f;
     }
     const long lane_off = (long)cg * 8 + oc;
-    for (long p = p_begin + row; p < p_end; p += 512) {
+    for (long p = p_begin + row; p < p_end; p += 256) {
         uint4 gq[4], yq[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const long q = p + 128 * u;
+            const long q = p + 64 * u;
             const bool ok = q < p_end;
             gq[u] = ok ? gz[q * octs + lane_off] : make_uint4(0, 0, 0, 0);
             yq[u] = ok ? y[q * octs + lane_off] : make_uint4(0, 0, 0, 0);
@@ -90,7 +91,7 @@ bn_bwd_reduce_kernel(const uint4 *__restrict__ gz, const uint4 *__restrict__ y, 
             }
         }
     }
-    // the 8 pixel rows of a wave (lane bits 3..5), then the 16 waves through LDS in wave order
+    // the 8 pixel rows of a wave (lane bits 3..5), then the 8 waves through LDS in wave order
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
 #pragma unroll
@@ -108,7 +109,7 @@ bn_bwd_reduce_kernel(const uint4 *__restrict__ gz, const uint4 *__restrict__ y, 
         const int which = threadIdx.x >> 6, cl = threadIdx.x & 63;
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) s += red[which][k][cl];
+        for (int k = 0; k < 8; ++k) s += red[which][k][cl];
         partial[((long)r * 2 + which) * C + cg * 64 + cl] = s;
     }
 }
@@ -298,7 +299,7 @@ thin_grad_expand_kernel(const float *__restrict__ gz, uint4 *__restrict__ g64, u
     }
 }
 
-// R pixel ranges per 64-channel group: about 512 blocks of 1024 threads in all, at least 128 pixels
+// R pixel ranges per 64-channel group: about 512 blocks of 512 threads in all, at least 128 pixels
 // per range and at most 128 ranges (bn_bwd_finalize_kernel's 8 slices x 16 rows).
 static int bn_bwd_ranges(long npix, int C) {
     long want = 512 / (C / 64);
@@ -326,7 +327,7 @@ extern "C" int ir2rgb_bn_bwd(const void *gz, const void *y, const float *scale, 
     hipStream_t s = as_stream(stream);
     // partial holds R*2*C floats followed by 3*C coefficient floats (see ir2rgb_hip.h)
     float *coef = partial + (long)R * 2 * C;
-    bn_bwd_reduce_kernel<<<R * (C / 64), 1024, 0, s>>>((const uint4 *)gz, (const uint4 *)y, scale, shift, mean, invstd,
+    bn_bwd_reduce_kernel<<<R * (C / 64), 512, 0, s>>>((const uint4 *)gz, (const uint4 *)y, scale, shift, mean, invstd,
                                                       partial, npix, C, act, dtype, per);
     bn_bwd_finalize_kernel<<<C / 64, 1024, 0, s>>>(partial, R, C, scale, mean, invstd, 1.0f / (float)npix, dgamma, dbeta,
                                                   coef);

@@ -921,8 +921,8 @@ static int pack_entries(const ir2rgb_conv_desc *d, const float *w, void *wpacked
         e.w = w;
         e.wp = reinterpret_cast<uint16_t *>(wpacked) + plans[i].w_offset;
         e.kind = 0;
-        long nb = (e.total + 2047) / 2048;
-        e.nblocks = (int)(nb < 1 ? 1 : (nb > 128 ? 128 : nb));
+        long nb = (e.total + 1023) / 1024;                     // four elements per thread
+        e.nblocks = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
     }
     return n;
 }

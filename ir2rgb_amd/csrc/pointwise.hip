@@ -44,6 +44,9 @@ bn_finalize_kernel(const float *__restrict__ partial, int rows, int C, double co
     __syncthreads();
     if (rg != 0 || c >= C) return;
     s1 = s2 = 0.0;
+    // unrolled in full the 64 doubles are all loaded first: 128 VGPRs = the cap of a 1024-thread block, and the
+    // compiler spilled 7 of them (a kernel with scratch pays for it at every dispatch)
+#pragma unroll 8
     for (int r = 0; r < 32; ++r) { s1 += red[0][r][cl]; s2 += red[1][r][cl]; }
     double mean = s1 / count;
     double var = s2 / count - mean * mean;
