@@ -148,11 +148,12 @@ int ir2rgb_conv2d_pack_weight_adjoint(const ir2rgb_conv_desc *d, const float *w,
 
 /* Batched packing -- all packed copies of a network refreshed by ONE launch after an optimizer step
  * (the reference has no counterpart: cuDNN reads torch-layout weights, networks.py convolutions).
- * A job is the argument list of ir2rgb_conv2d_pack_weight[_adjoint].  _build expands the jobs into
- * a table of at most 4 entries per job (one per weight class) in HOST memory (entry size from
- * _entry_bytes) and returns the entry count (negative IR2RGB_E* on error) and the launch's block
- * count; the caller copies the table to device memory once -- it stays valid while the job pointers
- * do -- and calls _run every time the weights changed.  All jobs of a table share one dtype. */
+ * A job is the argument list of ir2rgb_conv2d_pack_weight[_adjoint].  _table_bytes returns the size
+ * of the job table (negative IR2RGB_E* on error); _build writes it into HOST memory (16-byte
+ * aligned) and returns the entry count (<= 4 per job, one per weight class; negative on error) and
+ * the launch's block count; the caller copies the table to 16-byte aligned device memory once -- it
+ * stays valid while the job pointers do -- and calls _run every time the weights changed.  All jobs
+ * of a table share one dtype. */
 typedef struct ir2rgb_pack_job {
     ir2rgb_conv_desc desc;
     const float *w;
@@ -160,8 +161,8 @@ typedef struct ir2rgb_pack_job {
     int adjoint;
     int reserved;
 } ir2rgb_pack_job;
-int ir2rgb_conv2d_pack_batch_entry_bytes(void);
-int ir2rgb_conv2d_pack_batch_build(const ir2rgb_pack_job *jobs, int njobs, void *table_host, int max_entries,
+long ir2rgb_conv2d_pack_batch_table_bytes(const ir2rgb_pack_job *jobs, int njobs);
+int ir2rgb_conv2d_pack_batch_build(const ir2rgb_pack_job *jobs, int njobs, void *table_host, long table_bytes,
                                    int *nblocks);
 int ir2rgb_conv2d_pack_batch_run(const void *table_dev, int nentries, int nblocks, int dtype, void *stream);
 

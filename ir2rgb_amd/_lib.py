@@ -58,8 +58,8 @@ PROTOTYPES = {
     "ir2rgb_conv2d_stats_rows": (c_int, [_pdesc]),
     "ir2rgb_conv2d_pack_weight": (c_int, [_pdesc, P, P, P]),
     "ir2rgb_conv2d_pack_weight_adjoint": (c_int, [_pdesc, P, P, P]),
-    "ir2rgb_conv2d_pack_batch_entry_bytes": (c_int, []),
-    "ir2rgb_conv2d_pack_batch_build": (c_int, [_pjob, c_int, P, c_int, _pint]),
+    "ir2rgb_conv2d_pack_batch_table_bytes": (c_long, [_pjob, c_int]),
+    "ir2rgb_conv2d_pack_batch_build": (c_int, [_pjob, c_int, P, c_long, _pint]),
     "ir2rgb_conv2d_pack_batch_run": (c_int, [P, c_int, c_int, c_int, P]),
     "ir2rgb_conv2d_fwd": (c_int, [_pdesc, P, P, P, P, P, P]),
     "ir2rgb_conv2d_kernel_name": (ctypes.c_char_p, [_pdesc]),

@@ -78,15 +78,17 @@ class PackBatch:
             arr[j].desc, arr[j].w, arr[j].wpacked, arr[j].adjoint = desc, w.data_ptr(), packed.data_ptr(), int(bool(adjoint))
         self.dtype = jobs[0][0].dtype
         self.device = jobs[0][1].device
-        esz = lib.ir2rgb_conv2d_pack_batch_entry_bytes()
-        host = torch.zeros(4 * len(jobs) * esz, dtype=torch.uint8)
+        nbytes = lib.ir2rgb_conv2d_pack_batch_table_bytes(arr, len(jobs))
+        if nbytes < 0:
+            _lib.check(int(nbytes), "conv2d_pack_batch_table_bytes")
+        host = torch.zeros(int(nbytes), dtype=torch.uint8)
         nblocks = ctypes.c_int(0)
-        n = lib.ir2rgb_conv2d_pack_batch_build(arr, len(jobs), ctypes.c_void_p(host.data_ptr()), 4 * len(jobs),
+        n = lib.ir2rgb_conv2d_pack_batch_build(arr, len(jobs), ctypes.c_void_p(host.data_ptr()), int(nbytes),
                                                ctypes.byref(nblocks))
         if n < 0:
             _lib.check(int(n), "conv2d_pack_batch_build")
         self.nentries, self.nblocks = int(n), int(nblocks.value)
-        self.table = host[:self.nentries * esz].to(self.device)
+        self.table = host.to(self.device)
 
     def run(self):
         with _lib.on_device(self.table):

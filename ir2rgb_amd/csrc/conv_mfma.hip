@@ -604,8 +604,9 @@ pack_tile_kernel(const float *__restrict__ w, uint16_t *__restrict__ wp, int Cou
 
 // Batched packing: every weight of a network in ONE launch.  After an optimizer step ~280 packed copies
 // (forward and data-gradient operands) are stale; most are small and their individual launches cost
-// more than their bytes.  The table (device memory, built once by ir2rgb_conv2d_pack_batch_build) lists
-// one entry per (weight, class); a block finds its entry by its index among the entries' block ranges.
+// more than their bytes.  The table (device memory, built once by ir2rgb_conv2d_pack_batch_build) holds
+// one PackEntry per (weight, class) followed by one PackBlock per workgroup: a block's whole job
+// description is one uniform 48-byte load (scalar loads), no search.
 struct PackEntry {
     const float *w;
     uint16_t *wp;
@@ -615,28 +616,28 @@ struct PackEntry {
     int Cout, Cin, T, gx;       // kinds 1/2: source dims, taps, blocks along ci
     PackGeom g;                 // kind 0
 };
+struct PackBlock {
+    const float *w;
+    uint16_t *wp;
+    int Cout, Cin, T, kind;     // kinds 1/2
+    int bx, by;                 // kinds 1/2: tile coordinates; kind 0: block index within the entry, blocks of the entry
+    int entry, pad_;
+};
+static inline size_t pack_blocks_offset(int nentries) { return ((size_t)nentries * sizeof(PackEntry) + 15) & ~(size_t)15; }
 
 template <int DT>
 __global__ void __launch_bounds__(256)
-pack_batch_kernel(const PackEntry *__restrict__ E, int n) {
+pack_batch_kernel(const PackEntry *__restrict__ E, const PackBlock *__restrict__ B) {
     __shared__ uint16_t tile[PACK_TILE_HALFS];
-    __shared__ int which;
-    __shared__ PackEntry e;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int f = E[i].first_block;
-        if ((int)blockIdx.x >= f && (int)blockIdx.x < f + E[i].nblocks) which = i;
+    const PackBlock b = B[blockIdx.x];
+    if (b.kind == 0) {
+        const PackEntry &e = E[b.entry];
+        pack_weight_body<DT>(b.w, b.wp, e.g, e.total, b.bx * 256L + threadIdx.x, b.by * 256L);
+    } else if (b.kind == 1) {
+        pack_tile_body<DT, 0>(b.w, b.wp, b.Cout, b.Cin, b.T, b.bx, b.by, tile);
+    } else {
+        pack_tile_body<DT, 1>(b.w, b.wp, b.Cout, b.Cin, b.T, b.bx, b.by, tile);
     }
-    __syncthreads();
-    {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(E + which);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(&e);
-        for (int i = threadIdx.x; i < (int)(sizeof(PackEntry) / 4); i += 256) dst[i] = src[i];
-    }
-    __syncthreads();
-    const int lb = blockIdx.x - e.first_block;
-    if (e.kind == 0) pack_weight_body<DT>(e.w, e.wp, e.g, e.total, lb * 256L + threadIdx.x, e.nblocks * 256L);
-    else if (e.kind == 1) pack_tile_body<DT, 0>(e.w, e.wp, e.Cout, e.Cin, e.T, lb % e.gx, lb / e.gx, tile);
-    else pack_tile_body<DT, 1>(e.w, e.wp, e.Cout, e.Cin, e.T, lb % e.gx, lb / e.gx, tile);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -927,35 +928,70 @@ static int pack_entries(const ir2rgb_conv_desc *d, const float *w, void *wpacked
     return n;
 }
 
-extern "C" int ir2rgb_conv2d_pack_batch_entry_bytes(void) { return (int)sizeof(PackEntry); }
-
-extern "C" int ir2rgb_conv2d_pack_batch_build(const ir2rgb_pack_job *jobs, int njobs, void *table_host, int max_entries,
-                                              int *nblocks) {
-    if (!jobs || njobs < 1 || !table_host || !nblocks) return IR2RGB_EINVAL;
-    PackEntry *E = reinterpret_cast<PackEntry *>(table_host);
-    int n = 0, blocks = 0;
+static int pack_batch_expand(const ir2rgb_pack_job *jobs, int njobs, PackEntry *E, int max_entries, long *nblocks) {
+    if (!jobs || njobs < 1) return IR2RGB_EINVAL;
+    int n = 0;
+    long blocks = 0;
     for (int j = 0; j < njobs; ++j) {
         if (jobs[j].desc.dtype != jobs[0].desc.dtype) return IR2RGB_EINVAL;    // one element type per launch
         PackEntry tmp[4];
-        const int k = pack_entries(&jobs[j].desc, jobs[j].w, jobs[j].wpacked, jobs[j].adjoint != 0, tmp);
+        const int k = pack_entries(&jobs[j].desc, (const float *)jobs[j].w, jobs[j].wpacked, jobs[j].adjoint != 0, tmp);
         if (k < 0) return k;
-        if (n + k > max_entries) return IR2RGB_EINVAL;
         for (int i = 0; i < k; ++i) {
-            tmp[i].first_block = blocks;
+            tmp[i].first_block = (int)blocks;
             blocks += tmp[i].nblocks;
-            E[n++] = tmp[i];
+            if (E) {
+                if (n >= max_entries) return IR2RGB_EINVAL;
+                E[n] = tmp[i];
+            }
+            ++n;
         }
     }
+    if (blocks > 0x7fffffffL) return IR2RGB_EINVAL;
     *nblocks = blocks;
+    return n;
+}
+
+extern "C" long ir2rgb_conv2d_pack_batch_table_bytes(const ir2rgb_pack_job *jobs, int njobs) {
+    long blocks = 0;
+    const int n = pack_batch_expand(jobs, njobs, nullptr, 0, &blocks);
+    if (n < 0) return n;
+    return (long)(pack_blocks_offset(n) + (size_t)blocks * sizeof(PackBlock));
+}
+
+extern "C" int ir2rgb_conv2d_pack_batch_build(const ir2rgb_pack_job *jobs, int njobs, void *table_host, long table_bytes,
+                                              int *nblocks) {
+    if (!table_host || !nblocks) return IR2RGB_EINVAL;
+    const long need = ir2rgb_conv2d_pack_batch_table_bytes(jobs, njobs);
+    if (need < 0) return (int)need;
+    if (table_bytes < need) return IR2RGB_EINVAL;
+    PackEntry *E = reinterpret_cast<PackEntry *>(table_host);
+    long blocks = 0;
+    const int n = pack_batch_expand(jobs, njobs, E, (int)(table_bytes / (long)sizeof(PackEntry)), &blocks);
+    if (n < 0) return n;
+    PackBlock *B = reinterpret_cast<PackBlock *>(reinterpret_cast<char *>(table_host) + pack_blocks_offset(n));
+    for (int i = 0; i < n; ++i) {
+        const PackEntry &e = E[i];
+        for (int lb = 0; lb < e.nblocks; ++lb) {
+            PackBlock &b = B[e.first_block + lb];
+            memset(&b, 0, sizeof(b));
+            b.w = e.w; b.wp = e.wp; b.Cout = e.Cout; b.Cin = e.Cin; b.T = e.T; b.kind = e.kind; b.entry = i;
+            if (e.kind == 0) { b.bx = lb; b.by = e.nblocks; }
+            else { b.bx = lb % e.gx; b.by = lb / e.gx; }
+        }
+    }
+    *nblocks = (int)blocks;
     return n;
 }
 
 extern "C" int ir2rgb_conv2d_pack_batch_run(const void *table_dev, int nentries, int nblocks, int dtype, void *stream) {
     if (!table_dev || nentries < 1 || nblocks < 1) return IR2RGB_EINVAL;
     if (dtype != IR2RGB_BF16 && dtype != IR2RGB_F16) return IR2RGB_ENOSUP;
+    if ((uintptr_t)table_dev & 15) return IR2RGB_EALIGN;
     const PackEntry *E = reinterpret_cast<const PackEntry *>(table_dev);
-    if (dtype == IR2RGB_BF16) pack_batch_kernel<IR2RGB_BF16><<<nblocks, 256, 0, as_stream(stream)>>>(E, nentries);
-    else pack_batch_kernel<IR2RGB_F16><<<nblocks, 256, 0, as_stream(stream)>>>(E, nentries);
+    const PackBlock *B = reinterpret_cast<const PackBlock *>(reinterpret_cast<const char *>(table_dev) + pack_blocks_offset(nentries));
+    if (dtype == IR2RGB_BF16) pack_batch_kernel<IR2RGB_BF16><<<nblocks, 256, 0, as_stream(stream)>>>(E, B);
+    else pack_batch_kernel<IR2RGB_F16><<<nblocks, 256, 0, as_stream(stream)>>>(E, B);
     return ir2rgb_launch_status();
 }
 
