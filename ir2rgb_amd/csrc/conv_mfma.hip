@@ -669,10 +669,16 @@ static int conv_variant() {
 static int tile_pixels(long P, int Cout, int ksteps) {
     // TP = 256 (one resident workgroup per CU) pays off for long K loops with at least one tile per CU;
     // shorter loops / fewer tiles run two workgroups per CU with TP = 128 or 64.
+    static int forced = -1;          // IR2RGB_CONV_TP=256|128|64: experiments only
+    if (forced < 0) { const char *e = getenv("IR2RGB_CONV_TP"); forced = e ? atoi(e) : 0; }
+    if (forced == 256 || forced == 128 || forced == 64) return forced;
     const long nct = (Cout + 127) / 128;
     const long tiles256 = ((P + 255) / 256) * nct;
-    // long K loops, or many tiles of a large (HBM-streaming) input: the deep 3-stage ring wins
-    if (tiles256 >= 256 && (ksteps >= 40 || tiles256 >= 768)) return 256;
+    static int rule = -1;            // IR2RGB_CONV_TP_RULE=0: the earlier rule (TP = 256 also for short loops over >= 768 tiles)
+    if (rule < 0) { const char *e = getenv("IR2RGB_CONV_TP_RULE"); rule = e ? atoi(e) : 1; }
+    // long K loops: the deep 3-stage ring of the 256-pixel tile wins; short ones (k x 1 first layers and heads,
+    // sub-pixel classes of the up-samplers: 7..36 steps) run 10-20 % faster as two 128-pixel workgroups per CU
+    if (tiles256 >= 256 && (ksteps >= 40 || (rule == 0 && tiles256 >= 768))) return 256;
     if (((P + 127) / 128) * nct >= 256) return 128;
     return 64;
 }
@@ -774,14 +780,13 @@ static int make_plan(const ir2rgb_conv_desc *d, ClassPlan plans[4]) {
     // from the total tile count and the longest K loop
     int tp_all = 0;
     if (ncls > 1 && merge_classes()) {
-        long p_all = 0;
-        int ks_max = 0;
+        long p_all = 0, ks_sum = 0;
         for (int i = 0; i < ncls; ++i) {
             const ConvGeom &g = plans[i].geom;
             p_all += (long)g.N * g.Hsub * g.Wsub;
-            ks_max = g.kchunks * g.ntaps > ks_max ? g.kchunks * g.ntaps : ks_max;
+            ks_sum += (long)g.kchunks * g.ntaps;
         }
-        tp_all = tile_pixels(p_all, plans[0].geom.Cout, ks_max);
+        tp_all = tile_pixels(p_all, plans[0].geom.Cout, (int)(ks_sum / ncls));     // mean K steps over the classes
     }
     for (int i = 0; i < ncls; ++i) {
         ConvGeom &g = plans[i].geom;

@@ -12,4 +12,10 @@ with torch.no_grad():
     for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
         out = g(x, p, None, None, None, None, False)
 torch.cuda.synchronize()
-print("ok", float(out[0].abs().mean()))
+import time
+with torch.no_grad():
+    t0 = time.time()
+    for _ in range(10):
+        out = g(x, p, None, None, None, None, False)
+    torch.cuda.synchronize()
+print("ok", float(out[0].abs().mean()), "forward ms: %.3f" % ((time.time() - t0) * 100))

@@ -13,5 +13,5 @@ for i in range(12):
     out = tr.train_window(A[:, i:i + 3], B[:, i:i + 3])
     t_issue = time.time() - t0
     torch.cuda.synchronize()
-    print(i, round(time.time() - t0, 3), "s (issued in", round(t_issue, 3), "s)", {k: round(v.item(), 4) for k, v in out.items()}, flush=True)
+    print(i, round(time.time() - t0, 4), "s (issued in", round(t_issue, 4), "s)", {k: round(v.item(), 4) for k, v in out.items()}, flush=True)
 print("max mem GB", torch.cuda.max_memory_allocated() / 2**30)
