@@ -503,6 +503,7 @@ __global__ void __launch_bounds__(256)
 wgrad_sum_kernel(const float4 *__restrict__ D, float4 *__restrict__ out, long n4, int nsplit) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         float4 s = D[i];
+#pragma unroll 4
         for (int k = 1; k < nsplit; ++k) {
             const float4 v = D[k * n4 + i];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
@@ -545,6 +546,40 @@ wgrad_finish_kernel(const float *__restrict__ D, float *__restrict__ out, int Ca
         for (int k = 0; k < nsplit; ++k) s += p[k * slab];
         out[i] = s;
     }
+}
+
+// The same sums (same order over the splits: bit-identical) with coalesced reads: a block owns 64 consecutive
+// (a, b) pairs and all taps; wave w reads the taps w, w+4, ... of its 64 pairs (256 contiguous bytes per
+// split), the sums are transposed through LDS and leave as one contiguous run of 64 * ntaps floats.  The
+// gather form above reads one 4-byte element per lane from ntaps different planes.
+#define WF_MAX_TAPS 16
+__global__ void __launch_bounds__(256)
+wgrad_finish_tiled_kernel(const float *__restrict__ D, float *__restrict__ out, long AB, int ntaps, int nsplit) {
+    __shared__ float t[64 * (WF_MAX_TAPS + 1)];
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long ab0 = blockIdx.x * 64L, ab = ab0 + l;
+    const long slab = (long)ntaps * AB;
+    for (int tap = w; tap < ntaps; tap += 4) {
+        float s = 0.f;
+        if (ab < AB) {
+            const float *p = D + (long)tap * AB + ab;
+#pragma unroll 8
+            for (int k = 0; k < nsplit; ++k) s += p[k * slab];
+        }
+        t[l * (ntaps + 1) + tap] = s;
+    }
+    __syncthreads();
+    const long left = AB - ab0;
+    const int n = (int)(left < 64 ? left : 64) * ntaps;
+    for (int j = threadIdx.x; j < n; j += 256) out[ab0 * ntaps + j] = t[(j / ntaps) * (ntaps + 1) + j % ntaps];
+}
+
+static void launch_wgrad_finish(const float *D, float *out, int Ca, int Cb, int ntaps, int nsplit, hipStream_t s) {
+    const long AB = (long)Ca * Cb, elems = AB * ntaps;
+    if (ntaps <= WF_MAX_TAPS && (AB + 63) / 64 <= 0x7fffffffL)
+        wgrad_finish_tiled_kernel<<<(unsigned)((AB + 63) / 64), 256, 0, s>>>(D, out, AB, ntaps, nsplit);
+    else
+        wgrad_finish_kernel<<<stream_grid(elems, 256), 256, 0, s>>>(D, out, Ca, Cb, ntaps, nsplit, elems);
 }
 
 static int plan(const ir2rgb_conv_desc *d, WgradGeom *g) {
@@ -634,6 +669,6 @@ extern "C" int ir2rgb_conv2d_wgrad(const ir2rgb_conv_desc *d, const void *x, con
         if (d->dtype == IR2RGB_BF16) conv_wgrad_kernel<IR2RGB_BF16, 0><<<grid, 256, 0, s>>>(U, V, workspace, g);
         else conv_wgrad_kernel<IR2RGB_F16, 0><<<grid, 256, 0, s>>>(U, V, workspace, g);
     }
-    wgrad_finish_kernel<<<stream_grid(elems, 256), 256, 0, s>>>(workspace, dw, g.Ca, g.Cb, ntaps, g.ksplit, elems);
+    launch_wgrad_finish(workspace, dw, g.Ca, g.Cb, ntaps, g.ksplit, s);
     return ir2rgb_launch_status();
 }
