@@ -78,6 +78,28 @@ def test_generator_vs_reference_golden(dev, golden_dir, name, dtype):
     assert torch.equal(out[0], out[3])
 
 
+def test_graphed_generator_forward_equals_eager(dev, golden_dir):
+    """ir2rgb_amd.graphs.GraphedForward: the generator forward replayed from a HIP graph is the eager forward
+    bit for bit (same kernels, same order), on new inputs too, and BatchNorm statistics keep advancing."""
+    from ir2rgb_amd.graphs import GraphedForward
+    g = np.load(os.path.join(golden_dir, "net_G0_ngf64_32x64.npz"))
+    m = _gen(g, dev, torch.bfloat16)
+    A, prev = torch.from_numpy(g["A"]).to(dev), torch.from_numpy(g["prev"]).to(dev)
+    fwd = lambda a, p: m(a, p, None, None, None, None, False)[:4]      # noqa: E731  final, flow, weight, raw
+    graphed = GraphedForward(fwd, A, prev)
+    n0 = int(m.state_dict()["model_down_seg.2.num_batches_tracked"])
+    for scale in (1.0, 0.5):
+        a, p = A * scale, prev * scale
+        got = [t.clone() for t in graphed(a, p)]
+        with torch.no_grad():
+            want = fwd(a, p)
+        for x, y in zip(got, want):
+            assert torch.equal(x, y)
+    assert int(m.state_dict()["model_down_seg.2.num_batches_tracked"]) == n0 + 4     # 2 replays + 2 eager calls
+    with pytest.raises(ValueError):
+        graphed(A[:, :, :16], prev)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("name", ["D_nc6_64x96", "DT_nc13_48x80"])
 def test_discriminator_vs_reference_golden(dev, golden_dir, name, dtype):

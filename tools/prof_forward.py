@@ -18,4 +18,16 @@ with torch.no_grad():
     for _ in range(10):
         out = g(x, p, None, None, None, None, False)
     torch.cuda.synchronize()
-print("ok", float(out[0].abs().mean()), "forward ms: %.3f" % ((time.time() - t0) * 100))
+print("ok", float(out[0].abs().mean()), "eager forward ms: %.3f" % ((time.time() - t0) * 100))
+if "--graph" in sys.argv:
+    from ir2rgb_amd.graphs import GraphedForward
+    gf = GraphedForward(lambda a, b: g(a, b, None, None, None, None, False)[:4], x, p)
+    for _ in range(3):
+        gf(x, p)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(20):
+        gf(x, p)
+    torch.cuda.synchronize()
+    ms = (time.time() - t0) * 50
+    print("graphed forward ms: %.3f  (%.1f TFLOP/s of 6.632 TFLOP = %.1f %% of 2.5 PF)" % (ms, 6.632e3 / ms, 6.632e3 / ms / 25))
