@@ -86,10 +86,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    # Rehearsal switches (never set by the driver): IR2RGB_BENCH_BACKEND=gloo + IR2RGB_BENCH_SHARE_GPU=1 run the
+    # N > 1 path with all ranks on one GPU, to exercise everything but RCCL itself on a one-GPU box.
+    backend = os.environ.get("IR2RGB_BENCH_BACKEND", "nccl")
+    if os.environ.get("IR2RGB_BENCH_SHARE_GPU", "0") == "1":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from ir2rgb_amd import conv as C
@@ -188,7 +196,23 @@ def main():
         ms = e0.elapsed_time(e1) / 5
         extra["north_star_generator_forward_512x1024"] = {"ms": round(ms, 3), "TFLOPs": round(6.632 / ms * 1e3, 1),
                                                           "frac_of_peak": round(6.632 / ms * 1e3 / PEAK_TFLOPS, 4),
-                                                          "algorithmic_TFLOP": 6.632}
+                                                          "algorithmic_TFLOP": 6.632, "issue": "eager (host-bound)"}
+        try:    # the same forward replayed from a HIP graph (ir2rgb_amd.graphs): one launch, GPU-bound
+            from ir2rgb_amd.graphs import GraphedForward
+            gf = GraphedForward(lambda a, b: g(a, b, None, None, None, None, False)[:4], x, p)
+            for _ in range(2):
+                gf(x, p)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(10):
+                gf(x, p)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            extra["north_star_generator_forward_512x1024_hip_graph"] = {
+                "ms": round(ms, 3), "TFLOPs": round(6.632 / ms * 1e3, 1), "frac_of_peak": round(6.632 / ms * 1e3 / PEAK_TFLOPS, 4)}
+        except Exception as e:  # noqa: BLE001  an extra measurement must never take the bench line down
+            extra["north_star_generator_forward_512x1024_hip_graph"] = {"error": f"{type(e).__name__}: {e}"}
 
     frames = world * args.steps * 1  # n_frames_load = 1 frame per window per rank
     line = {
