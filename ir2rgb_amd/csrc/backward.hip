@@ -129,13 +129,13 @@ bn_bwd_finalize_kernel(const float *__restrict__ partial, int R, int C, const fl
         const int slice = threadIdx.x >> 7, which = (threadIdx.x >> 6) & 1, cl = threadIdx.x & 63;
         float t[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int k = slice + 8 * u;
-            t[u] = k < R ? partial[((long)k * 2 + which) * C + cg * 64 + cl] : 0.f;
+        for (int u = 0; u < 16; ++u) {     // unconditional loads of a clamped row, masked below: a predicated load
+            const int k = min(slice + 8 * u, R - 1);   // compiles to a branch with its own s_waitcnt (16 serial round trips)
+            t[u] = partial[((long)k * 2 + which) * C + cg * 64 + cl];
         }
         double a = 0.0;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) a += (double)t[u];
+        for (int u = 0; u < 16; ++u) a += slice + 8 * u < R ? (double)t[u] : 0.0;
         fin[slice][which][cl] = a;
     }
     __syncthreads();

@@ -205,20 +205,33 @@ xexpand_kernel(const float *__restrict__ in, uint4 *__restrict__ out, int Cin, i
     const int tw = min(XE_TW, Wout - ox0);
     const int span = (tw - 1) * sx + KW;
     const int ix0 = ox0 * sx - px;
-    for (int ci = 0; ci < Cin; ++ci) {
-        const float *src = in + (((long)n * Cin + ci) * H + y) * W;
-        for (int t = threadIdx.x; t < span; t += 256) {
+    // all (channel, column) elements of the block as one index range, eight unconditional (clamped) loads in
+    // flight per thread: a loop trip per channel cost one dependent HBM round trip each (9..13 per block)
+    const int total = Cin * span, pitch = (XE_TW - 1) * sx + KW;
+    const float *base = in + ((long)n * Cin * H + y) * W;
+    for (int i0 = threadIdx.x; i0 < total; i0 += 256 * 8) {
+        float v[8];
+        int dst[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = min(i0 + 256 * u, total - 1);
+            const int ci = i / span, t = i - ci * span;
             int ix = ix0 + t;
-            float v = 0.f;
+            bool inb = true;
             if (pad_mode) {
                 ix = ix < 0 ? -ix : ix;
                 ix = ix >= W ? 2 * W - 2 - ix : ix;
-                v = src[ix];
-            } else if (ix >= 0 && ix < W) {
-                v = src[ix];
+            } else {
+                inb = ix >= 0 && ix < W;
             }
-            seg[ci * ((XE_TW - 1) * sx + KW) + t] = v;
+            ix = max(0, min(ix, W - 1));
+            const float x = base[(long)ci * H * W + ix];
+            v[u] = inb ? x : 0.f;
+            dst[u] = i0 + 256 * u < total ? ci * pitch + t : -1;
         }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (dst[u] >= 0) seg[dst[u]] = v[u];
     }
     __syncthreads();
     const int lane = threadIdx.x % lanes, slot = threadIdx.x / lanes, slots = 256 / lanes;
