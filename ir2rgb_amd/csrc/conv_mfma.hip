@@ -123,14 +123,17 @@ template <int TP> struct ConvTile {
 
 // The kernel body; `block` is the workgroup's index inside its launch (or inside its class of a
 // multi-class launch) and `smem` the workgroup's LDS ring (ConvTile<TP>::LDS bytes, 1024-aligned).
-template <int DT, int TP, int NTY, int NTX>
+// THIN: at most 32 output channels (the 24-response 1x7 head pass, the 1-channel PatchGAN logits): only
+// the waves of the first 64-row half multiply, and only its first two 16-row fragments -- an eighth of
+// the MFMAs of the full 128-row tile; staging and epilogue are unchanged.
+template <int DT, int TP, int NTY, int NTX, bool THIN = false>
 __device__ __forceinline__ void
 conv_igemm_body(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Wp, const float *__restrict__ bias,
                 uint16_t *__restrict__ Y, float *__restrict__ stats_partial, const ConvGeom &g, const int block,
                 unsigned char *const smem) {
     constexpr int TC = 128;
     constexpr int NI = TP / 64;            // 16-pixel MFMA tiles per wave along pixels
-    constexpr int WROWS = TC / 64;         // weight rows staged per thread per K-step
+    constexpr int WROWS = THIN ? 1 : TC / 64;  // weight rows staged per thread per K-step (THIN: rows 0..63 only)
     constexpr int PROWS = TP / 64;         // pixel rows staged per thread per K-step
     constexpr int LOADS = WROWS + PROWS;   // LDS-DMA instructions per thread per K-step
     constexpr int STAGE = (TC + TP) * 128; // bytes per stage
@@ -277,18 +280,22 @@ conv_igemm_body(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Wp,
         else                           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // ... and for every wave; also: everyone is done reading stage ks-1
     };
+    constexpr int MI = THIN ? 2 : 4;       // 16-row output-channel fragments a wave multiplies
     auto compute = [&](int buf) {
+        if constexpr (THIN) {
+            if (wc != 0) return;           // wave-uniform: rows 64..127 of the tile do not exist
+        }
         const unsigned char *s = smem + buf * STAGE;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int sw = kk ? sw1 : sw0;
-            frag a[4], b[NI];
+            frag a[MI], b[NI];
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) a[mi] = *reinterpret_cast<const frag *>(s + offA + mi * 2048 + sw);
+            for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const frag *>(s + offA + mi * 2048 + sw);
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const frag *>(s + offB + ni * 2048 + sw);
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = H::mfma(a[mi], b[ni], acc[mi][ni]);
         }
@@ -455,12 +462,12 @@ conv_igemm_body(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Wp,
     }
 }
 
-template <int DT, int TP, int NTY, int NTX>
+template <int DT, int TP, int NTY, int NTX, bool THIN = false>
 __global__ void __launch_bounds__(512, (TP == 256 ? 2 : 4))
 conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Wp, const float *__restrict__ bias,
                   uint16_t *__restrict__ Y, float *__restrict__ stats_partial, const ConvGeom g) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[ConvTile<TP>::LDS];
-    conv_igemm_body<DT, TP, NTY, NTX>(X, Wp, bias, Y, stats_partial, g, (int)blockIdx.x, smem);
+    conv_igemm_body<DT, TP, NTY, NTX, THIN>(X, Wp, bias, Y, stats_partial, g, (int)blockIdx.x, smem);
 }
 
 // All sub-pixel classes of a stride-2 transposed convolution (or of the data gradient of a stride-2
@@ -1004,15 +1011,21 @@ extern "C" int ir2rgb_conv2d_pack_weight_adjoint(const ir2rgb_conv_desc *d, cons
     return pack_impl(d, w, wpacked, stream, true);
 }
 
-template <int DT, int NTY, int NTX>
+template <int DT, int NTY, int NTX, bool THIN = false>
 static void launch_conv_taps(const ClassPlan &c, int tp, unsigned grid, const uint16_t *x, const uint16_t *wp,
                              const float *bias, uint16_t *y, float *stats, hipStream_t s) {
     const ConvGeom &g = c.geom;
     switch (tp) {
-        case 256: conv_igemm_kernel<DT, 256, NTY, NTX><<<grid, 512, 0, s>>>(x, wp, bias, y, stats, g); break;
-        case 128: conv_igemm_kernel<DT, 128, NTY, NTX><<<grid, 512, 0, s>>>(x, wp, bias, y, stats, g); break;
-        default:  conv_igemm_kernel<DT, 64, NTY, NTX><<<grid, 512, 0, s>>>(x, wp, bias, y, stats, g); break;
+        case 256: conv_igemm_kernel<DT, 256, NTY, NTX, THIN><<<grid, 512, 0, s>>>(x, wp, bias, y, stats, g); break;
+        case 128: conv_igemm_kernel<DT, 128, NTY, NTX, THIN><<<grid, 512, 0, s>>>(x, wp, bias, y, stats, g); break;
+        default:  conv_igemm_kernel<DT, 64, NTY, NTX, THIN><<<grid, 512, 0, s>>>(x, wp, bias, y, stats, g); break;
     }
+}
+
+static bool conv_thin() {      // IR2RGB_CONV_THIN=0: thin layers on the full 128-row tile (A/B measurements)
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("IR2RGB_CONV_THIN"); v = e ? atoi(e) : 1; }
+    return v != 0;
 }
 
 template <int DT>
@@ -1023,7 +1036,10 @@ static void launch_conv(const ClassPlan &c, const uint16_t *x, const uint16_t *w
     const int nct = (g.Cout + 127) / 128;
     const unsigned grid = (unsigned)(c.npt * nct);
     const int nty = g.ntaps / g.ntx;
-    if (nty == 3 && g.ntx == 3)      launch_conv_taps<DT, 3, 3>(c, tp, grid, x, wp, bias, y, stats, s);
+    const bool thin = g.Cout <= 32 && conv_thin();
+    if (thin && nty == 4 && g.ntx == 4)      launch_conv_taps<DT, 4, 4, true>(c, tp, grid, x, wp, bias, y, stats, s);
+    else if (thin && nty == 1 && g.ntx == 7) launch_conv_taps<DT, 1, 7, true>(c, tp, grid, x, wp, bias, y, stats, s);
+    else if (nty == 3 && g.ntx == 3) launch_conv_taps<DT, 3, 3>(c, tp, grid, x, wp, bias, y, stats, s);
     else if (nty == 4 && g.ntx == 4) launch_conv_taps<DT, 4, 4>(c, tp, grid, x, wp, bias, y, stats, s);
     else if (nty == 7 && g.ntx == 1) launch_conv_taps<DT, 7, 1>(c, tp, grid, x, wp, bias, y, stats, s);
     else if (nty == 1 && g.ntx == 7) launch_conv_taps<DT, 1, 7>(c, tp, grid, x, wp, bias, y, stats, s);
