@@ -470,6 +470,79 @@ conv_igemm_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W
     conv_igemm_body<DT, TP, NTY, NTX, THIN>(X, Wp, bias, Y, stats_partial, g, (int)blockIdx.x, smem);
 }
 
+// Dot-product convolution for ONE fp32 output channel (the PatchGAN logit layers, 512 -> 1, 4x4, zero padding;
+// NLayerDiscriminator's last layer, networks.py:697-699): 67x131 pixels x 8192 MACs are 0.14 GFLOP, but on the
+// GEMM tile they cost 135 workgroups x 128 latency-bound K-steps (37 us).  Here a wave owns an output pixel:
+// lane = 8 consecutive input channels of each 512-channel slab, the 16-byte activation and weight loads of eight
+// taps in flight at once (unconditional from clamped coordinates, zero padding by masking), fp32 accumulation,
+// butterfly reduction, lane 0 stores.  Reads the same packed weights as the GEMM kernels.
+template <int DT>
+__device__ __forceinline__ float dot8(const uint4 &a, const uint4 &b) {
+    const uint32_t x[4] = {a.x, a.y, a.z, a.w}, y[4] = {b.x, b.y, b.z, b.w};
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float x0, x1, y0, y1;
+        if (DT == IR2RGB_BF16) {
+            x0 = __uint_as_float(x[j] << 16); x1 = __uint_as_float(x[j] & 0xffff0000u);
+            y0 = __uint_as_float(y[j] << 16); y1 = __uint_as_float(y[j] & 0xffff0000u);
+        } else {
+            x0 = (float)__builtin_bit_cast(_Float16, (uint16_t)(x[j] & 0xffff)); x1 = (float)__builtin_bit_cast(_Float16, (uint16_t)(x[j] >> 16));
+            y0 = (float)__builtin_bit_cast(_Float16, (uint16_t)(y[j] & 0xffff)); y1 = (float)__builtin_bit_cast(_Float16, (uint16_t)(y[j] >> 16));
+        }
+        s += x0 * y0;
+        s += x1 * y1;
+    }
+    return s;
+}
+
+template <int DT>
+__global__ void __launch_bounds__(256)
+conv_dot_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Wp, const float *__restrict__ bias,
+                float *__restrict__ Y, const ConvGeom g) {
+    const int lane = threadIdx.x & 63;
+    const long nwaves = (long)gridDim.x * 4;
+    const long P = (long)g.N * g.Hout * g.Wout;
+    const int HW = g.Hout * g.Wout, slabs = g.Cin >> 9, nty = g.ntaps / g.ntx;
+    const float b0 = bias ? bias[0] : 0.f;
+    for (long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6); p < P; p += nwaves) {
+        const int n = (int)(p / HW), rem = (int)(p - (long)n * HW);
+        const int oy = rem / g.Wout, ox = rem - oy * g.Wout;
+        float acc = 0.f;
+        for (int s = 0; s < slabs; ++s) {
+            const uint16_t *wbase = Wp + ((long)(s * 8 + (lane >> 3)) * g.ntaps) * 64 + (lane & 7) * 8;
+            for (int t0 = 0; t0 < g.ntaps; t0 += 8) {
+                uint4 xv[8], wv[8];
+                bool in[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t = min(t0 + u, g.ntaps - 1);
+                    const int ty = t / g.ntx, tx = t - ty * g.ntx;
+                    int iy = oy * g.s_in_y + g.dy0 + ty * g.dys, ix = ox * g.s_in_x + g.dx0 + tx * g.dxs;
+                    in[u] = t0 + u < g.ntaps && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
+                    iy = max(0, min(iy, g.Hin - 1));
+                    ix = max(0, min(ix, g.Win - 1));
+                    xv[u] = *reinterpret_cast<const uint4 *>(X + (((long)n * g.Hin + iy) * g.Win + ix) * g.ldx + g.ci_off + s * 512 + lane * 8);
+                    wv[u] = *reinterpret_cast<const uint4 *>(wbase + (long)t * 64);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float d = dot8<DT>(xv[u], wv[u]);
+                    acc += in[u] ? d : 0.f;
+                }
+            }
+        }
+        (void)nty;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+        if (lane == 0) {
+            float v = acc + b0;
+            if (g.act) v = v > 0.f ? v : (g.act == 1 ? 0.2f : (g.act == 2 ? 0.1f : 0.f)) * v;
+            Y[p * g.ldy + g.co_off] = v;
+        }
+    }
+}
+
 // All sub-pixel classes of a stride-2 transposed convolution (or of the data gradient of a stride-2
 // convolution) in ONE launch.  Launched class by class, each class fills only part of the chip (e.g.
 // 128 workgroups for 1024->512 @64x128) and the four launches run back to back; here the classes'
@@ -829,6 +902,15 @@ int conv3x3p_plan(const ir2rgb_conv_desc *d, P3Geom *g, int *npt_out);
 int conv3x3p_launch(int variant, const P3Geom &g, int dtype, const void *x, const void *wp, const float *bias, void *y,
                     float *stats, hipStream_t s);
 
+// One fp32 output channel, zero padding, 512-channel slabs, <= 16 taps: conv_dot_kernel (IR2RGB_CONV_DOT=0: GEMM tile)
+static bool conv_dot_ok(const ir2rgb_conv_desc *d) {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("IR2RGB_CONV_DOT"); v = e ? atoi(e) : 1; }
+    const int ldx = d->ldx ? d->ldx : d->Cin;
+    return v != 0 && d->out_f32 && d->Cout == 1 && !d->transposed && d->pad_mode == 0 && d->Cin >= 512 && (d->Cin % 512) == 0 &&
+           d->kh * d->kw <= 16 && (ldx % 8) == 0 && (d->ci_off % 8) == 0;
+}
+
 extern "C" const char *ir2rgb_conv2d_kernel_name(const ir2rgb_conv_desc *d) {
     if (!d) return "";
     P3Geom g3;
@@ -837,6 +919,7 @@ extern "C" const char *ir2rgb_conv2d_kernel_name(const ir2rgb_conv_desc *d) {
     ClassPlan plans[4];
     const int n = make_plan(d, plans);
     if (n < 0) return "";
+    if (n == 1 && conv_dot_ok(d)) return "conv_dot_kernel";
     return (n > 1 && merge_classes()) ? "conv_igemm_classes_kernel" : "conv_igemm_kernel";
 }
 
@@ -1065,6 +1148,17 @@ extern "C" int ir2rgb_conv2d_fwd(const ir2rgb_conv_desc *d, const void *x, const
     ClassPlan plans[4];
     int n = make_plan(d, plans);
     if (n < 0) return n;
+    if (n == 1 && stats_partial == nullptr && conv_dot_ok(d)) {
+        const ConvGeom &g = plans[0].geom;
+        const long P = (long)g.N * g.Hout * g.Wout;
+        const long waves = P < 8192 ? P : 8192;
+        const unsigned grid = (unsigned)((waves + 3) / 4);
+        if (d->dtype == IR2RGB_BF16)
+            conv_dot_kernel<IR2RGB_BF16><<<grid, 256, 0, as_stream(stream)>>>((const uint16_t *)x, (const uint16_t *)wpacked, bias, (float *)y, g);
+        else
+            conv_dot_kernel<IR2RGB_F16><<<grid, 256, 0, as_stream(stream)>>>((const uint16_t *)x, (const uint16_t *)wpacked, bias, (float *)y, g);
+        return ir2rgb_launch_status();
+    }
     if (n > 1 && merge_classes()) {
         // one launch for all classes: same pixel-tile size for all of them (plans were made with it)
         ConvClasses cs;

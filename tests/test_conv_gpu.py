@@ -85,6 +85,28 @@ def test_conv_vs_torch(dev, dtype, case):
     _check(y, stats, ref, dtype)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [(3, 512, 35, 67, 4, 1, 2), (1, 512, 9, 13, 4, 1, 2), (2, 1024, 12, 20, 3, 2, 1),
+                                  (1, 512, 8, 8, 1, 1, 0)])
+def test_one_channel_fp32_output(dev, dtype, case):
+    """The PatchGAN logit layers (512 -> 1, 4x4, zero padding, fp32 output): conv_dot_kernel (a wave per output
+    pixel) against torch's convolution on the same half-rounded operands; fp32 accumulation in another order."""
+    from ir2rgb_amd import conv as C
+    N, Cin, H, W, k, stride, pad = case
+    g = torch.Generator(device="cpu").manual_seed(Cin + H)
+    x = torch.randn(N, Cin, H, W, generator=g).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(1, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)).to(dev)
+    b = torch.randn(1, generator=g).to(dev)
+    desc = C.make_desc(x.shape, 1, k, stride, pad, C.PAD_ZERO, dtype, out_f32=True)
+    if os.environ.get("IR2RGB_CONV_DOT", "1") != "0":
+        assert C.kernel_name(desc) == "conv_dot_kernel"
+    y, _ = C.conv2d_fwd(desc, x, C.pack_weight(desc, w), b)
+    ref = F.conv2d(x.float(), w.to(dtype).float(), b, stride=stride, padding=pad)
+    assert y.dtype == torch.float32 and y.shape == ref.shape
+    rms = ref.pow(2).mean().sqrt().item()
+    assert (y - ref).abs().max().item() <= 1e-4 * max(rms, 1e-3) + 1e-5
+
+
 def test_conv_fused_leaky(dev):
     y, stats, ref = _ref_and_run(dev, torch.bfloat16, 1, 64, 20, 36, 64, 4, 2, 2, 0, act=1)
     _check(y, stats, ref, torch.bfloat16)
