@@ -269,9 +269,16 @@ thin_grad_expand_kernel(const float *__restrict__ gz, uint4 *__restrict__ g64, u
         __shared__ float red[256];
         const int c = blockIdx.x - expand_blocks;
         float s = 0.f;
-        for (long p = threadIdx.x; p < npix; p += 256) {
-            const long n = p / hw;
-            s += gz[(n * Cout + c) * hw + (p - n * hw)];
+        for (long p = threadIdx.x; p < npix; p += 256 * 8) {      // eight loads in flight (clamped, masked), index order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long pp = min(p + 256 * u, npix - 1);
+                const long n = pp / hw;
+                v[u] = gz[(n * Cout + c) * hw + (pp - n * hw)];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += p + 256 * u < npix ? v[u] : 0.f;
         }
         red[threadIdx.x] = s;
         __syncthreads();
