@@ -6,13 +6,13 @@ from torch.profiler import profile, ProfilerActivity
 from ir2rgb_amd import vid2vid as V
 dev = torch.device("cuda:0")
 tr = V.Vid2VidTrainer(dev, n_scales_spatial=2)
-A, B = V.synthetic_sequence(16, 512, 1024, 1234, dev)
-for i in range(6):
+A, B = V.synthetic_sequence(20, 512, 1024, 1234, dev)
+for i in range(10):
     tr.train_window(A[:, i:i + 3], B[:, i:i + 3])
 torch.cuda.synchronize()
 NW = 2
 with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU], with_stack=True, record_shapes=True) as prof:
-    for i in range(6, 6 + NW):
+    for i in range(10, 10 + NW):
         tr.train_window(A[:, i:i + 3], B[:, i:i + 3])
     torch.cuda.synchronize()
 agg = collections.defaultdict(lambda: [0.0, 0])
