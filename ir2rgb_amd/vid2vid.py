@@ -37,6 +37,7 @@ DEFAULTS = dict(  # options/base_options.py, options/train_options.py (SURVEY se
     fused_adam=True,     # one-launch HIP Adam (ir2rgb_amd.optim); False = torch.optim.Adam(foreach=True)
     fused_losses=True,   # grouped HIP loss kernels (ir2rgb_amd.losses); False = the same terms through torch ops
     batched_repack=True,  # all packed weight copies refreshed by one launch after the optimizer steps (layers.WeightRepacker)
+    build_flow_net=True,  # False: trainer.flow_net is left None for the caller to set (tests plug a stand-in for FlowNet2)
 )
 
 
@@ -158,14 +159,19 @@ class FlowNet(torch.nn.Module):
         assert im1.size(1) == 3 and im1.shape == im2.shape
         old_h, old_w = im1.shape[2:]
         new_h, new_w = old_h // 64 * 64, old_w // 64 * 64
-        if (old_h, old_w) != (new_h, new_w):
+        resize = old_h != new_h      # flownet.py:42 tests the height only ...
+        if not resize and old_w != new_w:
+            # ... and with a width that is not a multiple of 64 the reference dies in FlowNet2's torch.cat
+            raise ValueError(f"FlowNet: width {old_w} is not a multiple of 64 while height {old_h} is "
+                             "(the reference resizes only when the height is off, flownet.py:42)")
+        if resize:
             im1 = F.interpolate(im1, size=(new_h, new_w), mode="bilinear")
             im2 = F.interpolate(im2, size=(new_h, new_w), mode="bilinear")
         flow = self.flowNet(torch.stack([im1, im2], dim=2)).float().contiguous()
         _, _, norm = warp_diff_norm(im1.float().contiguous(), im2.float().contiguous(), flow, want_warped=False,
                                     want_diff=False)
         conf = (norm * norm < 0.02).float()  # flownet.py:50,56-57: sum of squares < 0.02
-        if (old_h, old_w) != (new_h, new_w):
+        if resize:
             flow = F.interpolate(flow, size=(old_h, old_w), mode="bilinear") * old_h / new_h
             conf = F.interpolate(conf, size=(old_h, old_w), mode="bilinear")
         return flow, conf
@@ -248,7 +254,9 @@ class Vid2VidTrainer:
             m.compute_dtype = o["compute_dtype"]
         # HIP-graph replay of FlowNet2 only in the single-process case: it saves host time, not GPU time, and
         # graph capture next to RCCL's watchdog thread cannot be exercised on the one-GPU development box
-        self.flow_net = FlowNet(o["flownet_dtype"], use_graph=None if world_size == 1 else False).to(device)
+        self.flow_net = None
+        if o["build_flow_net"]:
+            self.flow_net = FlowNet(o["flownet_dtype"], use_graph=None if world_size == 1 else False).to(device)
         self._side_wgrad = None          # set per window in generate(): safe only when n_load == 1
         self.vgg_loss = None
         if not o["no_vgg"]:
@@ -291,7 +299,12 @@ class Vid2VidTrainer:
             for g in self.netG:
                 autograd.enable_side_wgrad(g, self._side_wgrad)
         first = self.fake_B_prev is None
-        fake_pyr = avg_pool_pyramid(real_B_all[:, :tG - 1], ns) if first else self.fake_B_prev
+        if not first:
+            fake_pyr = list(self.fake_B_prev)
+        elif self.opt["no_first_img"]:       # the model also generates the first frame (generator.py:219-220)
+            fake_pyr = avg_pool_pyramid(torch.zeros_like(real_B_all[:, :tG - 1]), ns)
+        else:                                # training: the first frames are given (generator.py:221-222)
+            fake_pyr = avg_pool_pyramid(real_B_all[:, :tG - 1], ns)
         A_pyr = avg_pool_pyramid(real_A_all, ns)
         fake_raw, flows, weights = [], [], []
         for t in range(n_load):
@@ -460,12 +473,65 @@ class Vid2VidTrainer:
         for s in range(1, ts):
             if s in extra_flows:
                 fl_s[s], cf_s[s] = extra_flows[s]
-        self.frames_all[1:] = [fb_all, fl_all, cf_all]
+        # stored detached: the next window detaches the history anyway (discriminator.py:258), and a live reference
+        # would keep this window's generator graph (all saved activations) alive into the next one
+        self.frames_all[1:] = [fb_all.detach(), fl_all, cf_all]
         return rb_s, fb_s, fl_s, cf_s
 
     # ------------------------------------------------------------------ the loop body (a14)
+    def get_losses(self, L, LT):
+        """Vid2VidModelD.get_losses (discriminator.py:236-248): ``L`` the image-loss dict, ``LT`` the list of temporal
+        dicts of the active temporal scales.  Returns (loss_G, loss_D, [loss_D_T per active scale])."""
+        loss_D = (L["D_fake"] + L["D_real"]) * 0.5
+        loss_G = L["G_GAN"] + L["G_GAN_Feat"] + L["G_VGG"] + L["G_Warp"] + L["F_Flow"] + L["F_Warp"] + L["W"]
+        loss_D_T = []
+        for lt in LT:                                            # G_T_Warp is identically zero (discriminator.py:106)
+            loss_G = loss_G + lt["G_T_GAN"] + lt["G_T_GAN_Feat"]
+            loss_D_T.append((lt["D_T_fake"] + lt["D_T_real"]) * 0.5)
+        return loss_G, loss_D, loss_D_T
+
+    def backward_passes(self, loss_G, loss_D, loss_D_T, g_inputs=None):
+        """The three ``loss.backward()`` of train_vid2vid.py:104-111 (zero_grad included); each optimizer's gradient
+        all-reduce is issued as soon as its pass ends, so it overlaps the next pass.  ``g_inputs``: the tensors
+        the generator's pass differentiates with respect to (default: the generator parameters)."""
+        self.grads_G.zero()
+        self.grads_D.zero()
+        for gdt in self.grads_DT:
+            gdt.zero()
+        shared = self.opt["shared_fake_forward"]
+        d_nets = [self.netD] + self.netD_T
+        if g_inputs is None and shared:
+            g_inputs = self.grads_G.params
+        # shared discriminator forwards are walked twice: by the generator's pass (frames only) and by the
+        # discriminators' passes (parameters only); without sharing the flags are no-ops
+        # (inputs=...: the engine then runs only the nodes that lead to those tensors, so the
+        # discriminators' passes never enter the generator graph)
+        with autograd.backward_flags(d_nets if shared else [], autograd.SKIP_PARAM_GRADS):
+            loss_G.backward(retain_graph=shared, inputs=g_inputs)
+        self.grads_G.all_reduce_async(self.world)
+        with autograd.backward_flags(d_nets if shared else [], autograd.SKIP_INPUT_GRAD):
+            loss_D.backward(inputs=self.grads_D.params if shared else None)
+            self.grads_D.all_reduce_async(self.world)
+            for s, ld in enumerate(loss_D_T):
+                ld.backward(inputs=self.grads_DT[s].params if shared else None)
+                self.grads_DT[s].all_reduce_async(self.world)
+
+    def optimizer_steps(self, n_temporal):
+        """The three ``optimizer.step()`` of train_vid2vid.py:104-111, then one launch refreshing every packed weight."""
+        self.grads_G.wait()
+        self.optimizer_G.step()
+        self.grads_D.wait()
+        self.optimizer_D.step()
+        for s in range(n_temporal):
+            self.grads_DT[s].wait()
+            self.optimizer_D_T[s].step()
+        if self.repacker is not None:
+            self.repacker.run()          # every packed forward / data-gradient weight copy, one launch
+
     def train_window(self, input_A, input_B):
-        """train_vid2vid.py:54-111 for one window; returns a dict of detached scalar losses."""
+        """train_vid2vid.py:54-111 for one window.  Returns a dict of detached scalar losses: the totals ``G``, ``D``,
+        ``D_T{s}`` and every term under the reference's names (``G_GAN`` ... ``W``; temporal ones with the scale
+        appended, ``G_T_GAN0`` ...).  ``self.last_outputs`` keeps (fake_B, fake_B_raw, flow, weight), detached."""
         fake_prev_last = self.fake_B_prev
         fake_B, fake_B_raw, flow, weight, real_A, real_Bp = self.generate(input_A, input_B)
         real_B_prev, real_B = real_Bp[:, :-1], real_Bp[:, 1:]
@@ -478,45 +544,17 @@ class Vid2VidTrainer:
         L = self.image_losses(flat(real_B), flat(fake_B), flat(fake_B_raw), flat(real_A), flat(real_B_prev), flat(fbp),
                               flat(flow), flat(weight), flat(flow_ref), flat(conf_ref))
         rb_s, fb_s, fl_s, cf_s = self.skipped_frames(rb_s, extra_flows, fake_B, flow_ref, conf_ref)
-        LT = [self.temporal_losses(s, rb_s[s], fb_s[s], fl_s[s], cf_s[s]) for s in range(self.t_scales) if rb_s[s] is not None]
-        # get_losses (discriminator.py:236-248)
-        loss_D = (L["D_fake"] + L["D_real"]) * 0.5
-        loss_G = L["G_GAN"] + L["G_GAN_Feat"] + L["G_VGG"] + L["G_Warp"] + L["F_Flow"] + L["F_Warp"] + L["W"]
-        loss_D_T = []
-        for lt in LT:
-            loss_G = loss_G + lt["G_T_GAN"] + lt["G_T_GAN_Feat"]
-            loss_D_T.append((lt["D_T_fake"] + lt["D_T_real"]) * 0.5)
-        # backward passes; each optimizer's all-reduce overlaps the next backward
-        self.grads_G.zero()
-        self.grads_D.zero()
-        for gdt in self.grads_DT:
-            gdt.zero()
-        shared = self.opt["shared_fake_forward"]
-        d_nets = [self.netD] + self.netD_T
-        # shared discriminator forwards are walked twice: by the generator's pass (frames only) and by the
-        # discriminators' passes (parameters only); without sharing the flags are no-ops
-        # (inputs=...: the engine then runs only the nodes that lead to those parameters, so the
-        # discriminators' passes never enter the generator graph)
-        with autograd.backward_flags(d_nets if shared else [], autograd.SKIP_PARAM_GRADS):
-            loss_G.backward(retain_graph=shared, inputs=self.grads_G.params if shared else None)
-        self.grads_G.all_reduce_async(self.world)
-        with autograd.backward_flags(d_nets if shared else [], autograd.SKIP_INPUT_GRAD):
-            loss_D.backward(inputs=self.grads_D.params if shared else None)
-            self.grads_D.all_reduce_async(self.world)
-            for s, ld in enumerate(loss_D_T):
-                ld.backward(inputs=self.grads_DT[s].params if shared else None)
-                self.grads_DT[s].all_reduce_async(self.world)
-        self.grads_G.wait()
-        self.optimizer_G.step()
-        self.grads_D.wait()
-        self.optimizer_D.step()
-        for s in range(len(loss_D_T)):
-            self.grads_DT[s].wait()
-            self.optimizer_D_T[s].step()
-        if self.repacker is not None:
-            self.repacker.run()          # every packed forward / data-gradient weight copy, one launch
+        active = [s for s in range(self.t_scales) if rb_s[s] is not None]
+        LT = [self.temporal_losses(s, rb_s[s], fb_s[s], fl_s[s], cf_s[s]) for s in active]
+        loss_G, loss_D, loss_D_T = self.get_losses(L, LT)
+        self.backward_passes(loss_G, loss_D, loss_D_T)
+        self.optimizer_steps(len(loss_D_T))
+        self.last_outputs = tuple(t.detach() for t in (fake_B, fake_B_raw, flow, weight))
         out = {"G": loss_G.detach(), "D": loss_D.detach()}
         out.update({f"D_T{s}": l.detach() for s, l in enumerate(loss_D_T)})
+        out.update({k: v.detach() for k, v in L.items()})
+        for s, lt in zip(active, LT):
+            out.update({f"{k}{s}": v.detach() for k, v in lt.items()})
         return out
 
 

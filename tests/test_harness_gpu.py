@@ -1,0 +1,266 @@
+"""GPU parity of the training HARNESS against goldens produced by the
+REFERENCE's own code (tests/golden/make_window_goldens.py: models.loss + models.networks + FlowNet{S,SD,Fusion}
+imported from /root/reference and composed statement by statement as models/discriminator.py:90-284,
+models/generator.py:99-235, train_vid2vid.py:54-111, flownet2_pytorch/models.py:96-161 and flownet.py:38-57 do).
+
+Weights are not stored: the same seeds give bit-identical parameters (asserted by the generating script).
+
+Tolerances (half-precision MFMA path against the reference's fp32 CPU run; measured values printed by each test):
+  loss scalars          |d| <= tol * max(|ref|, 0.05)        f16 1e-2, bf16 3e-2
+  gradient tensors      relative L2                          f16 2e-2, bf16 6e-2  (through a 5-layer PatchGAN with
+                                                             BatchNorm over as few as 6x10 positions)
+  multi-window runs     loss scalars 3e-2 (f16) / 6e-2 (bf16): eight Adam steps (|dw| = lr per step whatever the
+                        gradient's size) feed rounding differences back into the weights
+  FlowNet sub-networks  relative L2 <= 1e-2 (bf16 operands, ~20 layers), composition <= 2e-2, confidence mask: at most
+                        2 % of the pixels on the other side of the 0.02 threshold
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+from window_stub import stub_flow_and_conf, stub_flownetc  # noqa: E402
+
+LOSS_TOL = {torch.float16: 1e-2, torch.bfloat16: 3e-2}
+GRAD_TOL = {torch.float16: 2e-2, torch.bfloat16: 6e-2}
+SEQ_TOL = {torch.float16: 3e-2, torch.bfloat16: 6e-2}
+
+
+def rel_l2(a, ref):
+    a = a.detach().float().cpu()
+    ref = torch.from_numpy(np.asarray(ref, dtype=np.float32))
+    assert tuple(a.shape) == tuple(ref.shape), (tuple(a.shape), tuple(ref.shape))
+    return ((a - ref).norm() / ref.norm().clamp_min(1e-12)).item()
+
+
+def close(val, ref, tol):
+    return abs(float(val) - float(ref)) <= tol * max(abs(float(ref)), 0.05)
+
+
+# ------------------------------------------------------------------------------------------------
+# a12
+# ------------------------------------------------------------------------------------------------
+def _tame(m):
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() == 1:
+                p.mul_(0.05)
+    return m
+
+
+def _subnet(kind, seed, dev):
+    from ir2rgb_amd.flownet2_pytorch import models as M
+    torch.manual_seed(seed)
+    return _tame({"S": M.FlowNetS, "SD": M.FlowNetSD, "F": M.FlowNetFusion}[kind]()).to(dev).eval()
+
+
+@pytest.mark.parametrize("kind", ["S", "SD", "F"])
+def test_flownet_subnetwork_vs_reference_golden(dev, golden_dir, kind):
+    from ir2rgb_amd import flownet2_hip as FH
+    g = np.load(os.path.join(golden_dir, f"flownet_{kind}.npz"))
+    net = _subnet(kind, int(g["seed"]), dev)
+    assert list(net.state_dict().keys()) == [str(k) for k in g["keys"]]       # checkpoint-compatible names
+    run = {"S": FH.flownets, "SD": FH.flownetsd, "F": FH.flownetfusion}[kind]
+    x = torch.from_numpy(g["x"]).to(dev)
+    errs = {}
+    for dt in (torch.bfloat16, torch.float16):
+        with torch.no_grad():
+            out = run(net, x, dt)
+        errs[str(dt)] = rel_l2(out, g["out"])
+    print("FlowNet", kind, errs)
+    assert all(e <= 1e-2 for e in errs.values()), errs
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_flownet2_composition_vs_reference_golden(dev, golden_dir, tag):
+    """FlowNet2.forward's glue (mean subtraction, warps, norms, concatenation order, x20 / 20 factors, bilinear vs nearest
+    up-sampling) and FlowNet.compute_flow_and_conf (confidence threshold; case b: the 80 -> 64 row resize branch), with
+    FlowNetC replaced by the same stub on both sides."""
+    from ir2rgb_amd import vid2vid as V
+    g = np.load(os.path.join(golden_dir, "flownet2_glue.npz"))
+    fn = V.FlowNet(use_graph=False).to(dev)
+    f2 = fn.flowNet
+    seeds = [int(s) for s in g["seeds"]]
+    f2.flownets_1, f2.flownets_2 = _subnet("S", seeds[0], dev), _subnet("S", seeds[1], dev)
+    f2.flownets_d, f2.flownetfusion = _subnet("SD", seeds[2], dev), _subnet("F", seeds[3], dev)
+    orig = f2._net
+    f2._net = lambda sub, x: stub_flownetc(x.float()) if sub is f2.flownetc else orig(sub, x)
+    im1, im2 = torch.from_numpy(g[f"im1_{tag}"]).to(dev), torch.from_numpy(g[f"im2_{tag}"]).to(dev)
+    flow, conf = fn.compute_flow_and_conf(im1, im2)
+    err = rel_l2(flow, g[f"flow_{tag}"])
+    ref_conf = torch.from_numpy(g[f"conf_{tag}"])
+    mism = ((conf.cpu() - ref_conf).abs() > 0.5).float().mean().item()
+    print("FlowNet2 composition", tag, "flow relative L2", err, "confidence mismatch", mism)
+    assert flow.shape == (1, 2) + tuple(im1.shape[2:]) and conf.shape == (1, 1) + tuple(im1.shape[2:])
+    assert err <= 2e-2 and mism <= 0.02
+    if tag == "a":
+        with torch.no_grad():
+            raw = f2(torch.stack([im1, im2], 2))
+        assert rel_l2(raw, g["flow2_a"]) <= 2e-2
+    with pytest.raises(ValueError):                    # width off, height fine: the reference does not resize (flownet.py:42)
+        fn.compute_flow_and_conf(im1[:, :, :64, :100].contiguous(), im2[:, :, :64, :100].contiguous())
+
+
+# ------------------------------------------------------------------------------------------------
+# a13
+# ------------------------------------------------------------------------------------------------
+def _seeded_discriminators(tr, seeds, dev):
+    """Loads the weights the golden script built (torch.manual_seed(seed) right before each factory call)."""
+    from ir2rgb_amd import networks as N
+    o = tr.opt
+    torch.manual_seed(seeds[0])
+    d = N.build_discriminator_module(o["input_nc"] + o["output_nc"], o["first_layer_dis_filters"], o["n_layers_D"], o["norm"],
+                                     o["num_D"], not o["no_ganFeat"])
+    tr.netD.load_state_dict(d.state_dict())
+    for s in range(tr.t_scales):
+        torch.manual_seed(seeds[1] + s)
+        d = N.build_discriminator_module(o["output_nc"] * tr.tD + 2 * (tr.tD - 1), o["first_layer_dis_filters"], o["n_layers_D"],
+                                         o["norm"], o["num_D"], not o["no_ganFeat"])
+        tr.netD_T[s].load_state_dict(d.state_dict())
+
+
+def _check_param_grads(prefix, module, g, tol, what):
+    names = [str(k) for k in g[f"{prefix}grad_names"]]
+    norms = g[f"{prefix}grad_norms"]
+    params = dict(module.named_parameters())
+    assert list(params.keys()) == names
+    bad, worst = {}, 0.0
+    total_ref = float(np.sqrt((norms ** 2).sum()))
+    for k, n in zip(names, norms):
+        got = params[k].grad
+        assert got is not None, f"{what}: no gradient for {k}"
+        gn = got.double().norm().item()
+        # BatchNorm removes the bias of the convolution in front of it: its gradient is rounding noise on both sides
+        if n < 1e-4 * total_ref:
+            assert gn <= 1e-3 * total_ref + 10 * n, (k, gn, n)
+            continue
+        e = abs(gn - n) / n
+        worst = max(worst, e)
+        if e > 2 * tol:
+            bad[k] = (gn, float(n))
+    full = {}
+    for key in g.files:
+        if key.startswith(f"{prefix}grad/"):
+            k = key[len(prefix) + 5:]
+            ref = g[key]
+            if np.linalg.norm(ref) < 1e-4 * total_ref:
+                continue
+            full[k] = rel_l2(params[k].grad, ref)
+    print(what, "worst gradient-norm error", worst, "full-tensor relative L2", {k: round(v, 5) for k, v in full.items()})
+    assert not bad, f"{what}: gradient norms off: {bad}"
+    assert full and all(v <= tol for v in full.values()), f"{what}: gradient tensors off: {full}"
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("tag", ["s1", "s2_nofirst"])
+def test_loss_assembly_vs_reference_golden(dev, golden_dir, tag, dtype):
+    """image_losses / temporal_losses / get_losses / the three backward passes against the reference's
+    Vid2VidModelD.forward, compute_loss_D(_T), GAN_and_FM_loss, get_losses on the same tensors and weights."""
+    from ir2rgb_amd import vid2vid as V
+    g = np.load(os.path.join(golden_dir, f"losses_{tag}.npz"))
+    ns = int(g["n_scales_spatial"])
+    tr = V.Vid2VidTrainer(dev, compute_dtype=dtype, first_layer_gen_filters=64 * ns, n_scales_spatial=ns,
+                          no_first_img=bool(g["no_first_img"]), build_flow_net=False)
+    _seeded_discriminators(tr, [int(s) for s in g["seeds"]], dev)
+    t = {k[3:]: torch.from_numpy(g[k]).to(dev) for k in g.files if k.startswith("in/")}
+    leaves = ["fake_B", "fake_B_raw", "flow", "weight", "fake_B_s"]
+    for k in leaves:
+        t[k].requires_grad_()
+    L = tr.image_losses(t["real_B"], t["fake_B"], t["fake_B_raw"], t["real_A"], t["real_B_prev"], t["fake_B_prev"], t["flow"],
+                        t["weight"], t["flow_ref"], t["conf_ref"])
+    LT = [tr.temporal_losses(0, t["real_B_s"], t["fake_B_s"], t["flow_ref_s"], t["conf_ref_s"])]
+    loss_G, loss_D, loss_D_T = tr.get_losses(L, LT)
+    got = {**{k: v.item() for k, v in L.items()}, **{k: v.item() for k, v in LT[0].items()}, "G": loss_G.item(),
+           "D": loss_D.item(), "D_T0": loss_D_T[0].item()}
+    tol = LOSS_TOL[dtype]
+    errs = {k: abs(got[k] - float(g[f"loss/{k}"])) / max(abs(float(g[f"loss/{k}"])), 0.05) for k in got}
+    print(tag, dtype, "loss errors", {k: round(v, 5) for k, v in errs.items()})
+    assert all(v <= tol for v in errs.values()), errs
+    assert float(g["loss/G_T_Warp"]) == 0.0 and float(g["loss/G_VGG"]) == 0.0
+    tr.backward_passes(loss_G, loss_D, loss_D_T, g_inputs=[t[k] for k in leaves if k != "weight" or bool(g["no_first_img"])])
+    gt = GRAD_TOL[dtype]
+    gerr = {}
+    for k in leaves:
+        ref = g[f"gradG/{k}"]
+        if not np.any(ref):          # weight without no_first_img: no term of the D-side objective depends on it
+            assert k == "weight" and t[k].grad is None
+            continue
+        gerr[k] = rel_l2(t[k].grad, ref)
+    print(tag, dtype, "generator-side gradient errors", {k: round(v, 5) for k, v in gerr.items()})
+    assert all(v <= gt for v in gerr.values()), gerr
+    _check_param_grads("D/", tr.netD, g, gt, f"{tag} {dtype} netD")
+    _check_param_grads("DT0/", tr.netD_T[0], g, gt, f"{tag} {dtype} netD_T0")
+    # the second temporal discriminator took no part: zero gradients, as after zero_grad() + no backward
+    assert all(p.grad is None or not p.grad.any() for p in tr.netD_T[1].parameters())
+
+
+# ------------------------------------------------------------------------------------------------
+# a8 + a13 + a14: whole windows, optimizer steps included
+# ------------------------------------------------------------------------------------------------
+def _seeded_trainer(g, dev, dtype):
+    from ir2rgb_amd import networks as N
+    from ir2rgb_amd import vid2vid as V
+    seed, ns, ngf = int(g["seed"]), int(g["n_scales_spatial"]), int(g["ngf"])
+    tr = V.Vid2VidTrainer(dev, compute_dtype=dtype, first_layer_gen_filters=ngf, n_scales_spatial=ns,
+                          no_first_img=bool(g["no_first_img"]), build_flow_net=False)
+    o = tr.opt
+    kw = {k: o[k] for k in ("gen_blocks", "n_local_enhancers", "feat_num", "n_blocks_local", "fg", "no_flow")}
+    tG = o["n_input_gen_frames"]
+    torch.manual_seed(seed)            # the golden script seeds once, then builds every spatial scale in order
+    for s in range(ns):
+        name = o["gen_network"] + ("-local" if s else "")
+        m = N.build_generator_module(o["input_nc"] * tG, o["output_nc"], (tG - 1) * o["output_nc"], ngf // 2 ** s, name,
+                                     o["gen_ds_layers"], o["norm"], s, **kw)
+        tr.netG[s].load_state_dict(m.state_dict())
+        del m
+    _seeded_discriminators(tr, [seed + 1, seed + 2], dev)
+    tr.flow_net = stub_flow_and_conf
+    return tr
+
+
+@pytest.mark.parametrize("case,dtype", [("ngf64_64x128", torch.float16), ("ngf64_64x128", torch.bfloat16),
+                                        ("ngf64_nofirst_64x128", torch.float16), ("2scale_ngf128_64x128", torch.float16)])
+def test_training_windows_vs_reference_golden(dev, golden_dir, case, dtype):
+    """Vid2VidTrainer.train_window, window after window (recurrence over generated frames, temporal bookkeeping over
+    up to 7 frames, three backward passes and three Adam steps per window) against the reference's loop body."""
+    g = np.load(os.path.join(golden_dir, f"window_{case}.npz"))
+    tr = _seeded_trainer(g, dev, dtype)
+    A, B = torch.from_numpy(g["seq_A"]).to(dev), torch.from_numpy(g["seq_B"]).to(dev)
+    tG = tr.opt["n_input_gen_frames"]
+    tol, gtol = SEQ_TOL[dtype], GRAD_TOL[dtype]
+    worst = {}
+    for i in range(int(g["n_windows"])):
+        out = tr.train_window(A[:, i:i + tG], B[:, i:i + tG])
+        ref = {k.split("/")[-1]: float(g[k]) for k in g.files if k.startswith(f"w{i}/loss/")}
+        got = {k: v.item() for k, v in out.items()}
+        missing = {k for k in ref if k not in got and not k.startswith("G_T_Warp")}
+        assert not missing, f"window {i}: terms not produced: {missing}"
+        assert {k for k in got if k not in ref} == set(), f"window {i}: unexpected terms {set(got) - set(ref)}"
+        errs = {k: abs(got[k] - ref[k]) / max(abs(ref[k]), 0.05) for k in got}
+        fake_B, fake_B_raw, flow, weight = tr.last_outputs
+        errs["fake_B"] = rel_l2(fake_B, g[f"w{i}/fake_B"].astype(np.float32))
+        errs["fake_B_raw"] = rel_l2(fake_B_raw, g[f"w{i}/fake_B_raw"].astype(np.float32))
+        errs["flow"] = rel_l2(flow, g[f"w{i}/flow"].astype(np.float32))
+        errs["weight"] = rel_l2(weight, g[f"w{i}/weight"].astype(np.float32))
+        print(case, dtype, "window", i, {k: round(v, 4) for k, v in errs.items()})
+        for k, v in errs.items():
+            worst[k] = max(worst.get(k, 0.0), v)
+        bad = {k: v for k, v in errs.items() if v > tol}
+        assert not bad, f"window {i}: over tolerance {tol}: {bad}"
+        if i == 0:      # gradients as they stood between backward() and step() (Adam does not touch them)
+            for s, net in enumerate(tr.netG):
+                _check_param_grads(f"w0/G{s}/", net, g, 2 * gtol, f"{case} {dtype} netG{s}")
+            _check_param_grads("w0/D/", tr.netD, g, gtol, f"{case} {dtype} netD")
+    print(case, dtype, "worst per term", {k: round(v, 4) for k, v in worst.items()})
+    # what eight Adam steps did to a few tensors: the update direction must agree (each step moves a weight by ~lr)
+    sdG, sdD = tr.netG[-1].state_dict(), tr.netD.state_dict()
+    for key in g.files:
+        if key.startswith("after/"):
+            _, which, name = key.split("/", 2)
+            now = (sdG if which == "G" else sdD)[name]
+            assert rel_l2(now, g[key]) <= 2e-2, key
