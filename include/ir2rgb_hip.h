@@ -186,6 +186,20 @@ int ir2rgb_bn_finalize(const float *stats_partial, int rows, int C, long count, 
                        float *scale, float *shift, float *mean_out, float *invstd_out, int stat_updates,
                        void *stream);
 
+/* The same with two more inputs.
+ * conv_bias (may be NULL): the statistics are those of the convolution output WITHOUT its bias.  BatchNorm subtracts
+ *   the batch mean, so the bias of the convolution in front of it (nn.Conv2d(..., bias=True) + norm_layer,
+ *   networks.py:141-171) cancels exactly; leaving it out of the half-precision activations keeps a constant input
+ *   (e.g. the all-zero previous frames of no_first_img, generator.py:219-220) exactly constant, as it is in fp32.
+ *   Only the running mean sees it: running_mean follows mean + conv_bias, as nn.BatchNorm2d's does.
+ * frozen != 0: module.eval() -- no batch statistics (stats_partial / rows / count unused), scale and shift come
+ *   from running_mean / running_var (both required):  scale = gamma*rsqrt(running_var+eps),
+ *   shift = beta - (running_mean - conv_bias)*scale; mean_out = running_mean - conv_bias; nothing is updated. */
+int ir2rgb_bn_finalize_ex(const float *stats_partial, int rows, int C, long count, const float *gamma,
+                          const float *beta, const float *conv_bias, float *running_mean, float *running_var,
+                          float momentum, float eps, float *scale, float *shift, float *mean_out,
+                          float *invstd_out, int stat_updates, int frozen, void *stream);
+
 /* y = act(x*scale[c] + shift[c]) + res1 + res2 on NHWC half tensors of npix pixels x C channels
  * (C % 8 == 0).  act: 0 none, 1 ReLU, 2 LeakyReLU(0.2).  res1/res2 may be NULL; y may alias x.
  * Covers norm+activation (networks.py:141-171, :253-271, :678-699), the ResnetBlock skip
@@ -241,7 +255,8 @@ int ir2rgb_bn_bwd_blocks(long npix, int C);
  *   g' = gz * act'(y*scale+shift);  dbeta = sum g';  dgamma = sum g'*yhat;
  *   gy = scale * (g' - dbeta/n - yhat*dgamma/n),  yhat = (y-mean)*invstd.
  * With scale == NULL (no norm layer): gy = gz * act'(y) and dbeta = sum gy (the bias gradient).
- * act: 0 none, 1 ReLU, 2 LeakyReLU(0.2).  gy may alias gz. */
+ * act: 0 none, 1 ReLU, 2 LeakyReLU(0.2); act | 16: the statistics were frozen (evaluation-mode BatchNorm,
+ * ir2rgb_bn_finalize_ex(frozen)): gy = scale * g', dgamma / dbeta as above.  gy may alias gz. */
 int ir2rgb_bn_bwd(const void *gz, const void *y, const float *scale, const float *shift, const float *mean,
                   const float *invstd, void *gy, float *dgamma, float *dbeta, float *partial, long npix, int C,
                   int act, int dtype, void *stream);

@@ -304,12 +304,17 @@ class ConvStageFn(Function):
                                dt, spec["transposed"], spec.get("output_padding", 0), act=_fused_act(spec),
                                out_f32=spec.get("out_f32", False))
             wp = L.packed_weight(conv, desc)
-        y, stats = C.conv2d_fwd(desc, xin, wp, bias, want_stats=bn is not None)
         scale = shift = mean = invstd = None
+        ctx.frozen = False
         if bn is not None:
-            scale, shift, mean, invstd = L.bn_finalize(stats, desc.N * desc.Hout * desc.Wout, bn, spec["training"])
+            # the bias of a convolution in front of BatchNorm cancels: it is left out of the activations and
+            # handed to the statistics kernel, which needs it for the running mean only (ir2rgb_bn_finalize_ex)
+            ctx.frozen = L.bn_frozen(bn, spec["training"])
+            y, stats = C.conv2d_fwd(desc, xin, wp, None, want_stats=not ctx.frozen)
+            scale, shift, mean, invstd = L.bn_finalize(stats, desc.N * desc.Hout * desc.Wout, bn, spec["training"], bias)
             z = L.bn_apply(y, scale, shift, spec["act"], res1, res2)
         else:
+            y, _ = C.conv2d_fwd(desc, xin, wp, bias)
             z = y
         ctx.spec, ctx.conv = spec, conv
         ctx.x_shape = tuple(x.shape)
@@ -335,9 +340,11 @@ class ConvStageFn(Function):
             dgamma = dbeta = None
         elif ctx.has_bn:
             gz = _as_half_nhwc(gz, hdt)
-            gy, dgamma, dbeta = bn_bwd(gz, y, scale, shift, mean, invstd, spec["act"])
+            gy, dgamma, dbeta = bn_bwd(gz, y, scale, shift, mean, invstd, spec["act"] | (16 if ctx.frozen else 0))
             gy_thin = gy
-            dbias = None  # BatchNorm removes the per-channel mean: the bias gradient is exactly 0
+            # training mode: BatchNorm removes the per-channel mean, the bias gradient is exactly 0 (None = zeros);
+            # evaluation mode: the layer is affine in the bias, d/dbias = scale * sum g'
+            dbias = dbeta * scale if ctx.frozen else None
         else:
             gz = _as_half_nhwc(gz, hdt)
             # LeakyReLU / ReLU keep the sign (ReLU: y > 0 <=> pre-activation > 0): mask from the stored output

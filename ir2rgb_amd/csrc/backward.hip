@@ -328,6 +328,8 @@ extern "C" int ir2rgb_bn_bwd(const void *gz, const void *y, const float *scale, 
     const int R = ir2rgb_bn_bwd_blocks(npix, C);
     if (R < 0) return R;
     if (dtype != IR2RGB_BF16 && dtype != IR2RGB_F16) return IR2RGB_ENOSUP;
+    const bool frozen = act >= 0 && (act & 16);   // evaluation-mode BatchNorm: the mean / variance terms vanish
+    if (frozen) act &= 15;
     if (!gz || !y || !gy || !dgamma || !dbeta || !partial || act < 0 || act > 2) return IR2RGB_EINVAL;
     const int R0 = bn_bwd_ranges(npix, C);
     const long per = (npix + R0 - 1) / R0;
@@ -336,7 +338,7 @@ extern "C" int ir2rgb_bn_bwd(const void *gz, const void *y, const float *scale, 
     float *coef = partial + (long)R * 2 * C;
     bn_bwd_reduce_kernel<<<R * (C / 64), 512, 0, s>>>((const uint4 *)gz, (const uint4 *)y, scale, shift, mean, invstd,
                                                       partial, npix, C, act, dtype, per);
-    bn_bwd_finalize_kernel<<<C / 64, 1024, 0, s>>>(partial, R, C, scale, mean, invstd, 1.0f / (float)npix, dgamma, dbeta,
+    bn_bwd_finalize_kernel<<<C / 64, 1024, 0, s>>>(partial, R, C, scale, mean, invstd, frozen ? 0.f : 1.0f / (float)npix, dgamma, dbeta,
                                                   coef);
     long total8 = npix * (C / 8);
     bn_bwd_apply_kernel<<<stream_grid(total8, 256), 256, 0, s>>>((const uint4 *)gz, (const uint4 *)y, scale, shift, coef,

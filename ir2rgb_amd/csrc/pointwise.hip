@@ -27,9 +27,10 @@ static __device__ __forceinline__ uint16_t f2h(float f, int dt) {
 // ----------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
 bn_finalize_kernel(const float *__restrict__ partial, int rows, int C, double count, const float *__restrict__ gamma,
-                   const float *__restrict__ beta, float *__restrict__ running_mean, float *__restrict__ running_var,
-                   float momentum, float eps, float *__restrict__ scale, float *__restrict__ shift,
-                   float *__restrict__ mean_out, float *__restrict__ invstd_out, int stat_updates) {
+                   const float *__restrict__ beta, const float *__restrict__ conv_bias, float *__restrict__ running_mean,
+                   float *__restrict__ running_var, float momentum, float eps, float *__restrict__ scale,
+                   float *__restrict__ shift, float *__restrict__ mean_out, float *__restrict__ invstd_out,
+                   int stat_updates) {
     __shared__ double red[2][32][33];
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
@@ -72,10 +73,12 @@ bn_finalize_kernel(const float *__restrict__ partial, int rows, int C, double co
     shift[c] = b - (float)mean * sc;
     if (mean_out) mean_out[c] = (float)mean;
     if (invstd_out) invstd_out[c] = invstd;
-    // stat_updates > 1: this forward stands for that many identical forwards of the reference
+    // stat_updates > 1: this forward stands for that many identical forwards of the reference.
+    // conv_bias: the statistics are those of the bias-free convolution output; nn.BatchNorm2d saw y + bias
     if (running_mean) {
         float r = running_mean[c];
-        for (int u = 0; u < stat_updates; ++u) r = (1.f - momentum) * r + momentum * (float)mean;
+        const float m = (float)mean + (conv_bias ? conv_bias[c] : 0.f);
+        for (int u = 0; u < stat_updates; ++u) r = (1.f - momentum) * r + momentum * m;
         running_mean[c] = r;
     }
     if (running_var) {
@@ -84,6 +87,24 @@ bn_finalize_kernel(const float *__restrict__ partial, int rows, int C, double co
         for (int u = 0; u < stat_updates; ++u) r = (1.f - momentum) * r + momentum * (float)unbiased;
         running_var[c] = r;
     }
+}
+
+// Evaluation-mode BatchNorm2d (module.eval(), running statistics): scale / shift for a bias-free input y,
+//   z = (y + bias - running_mean) * gamma * rsqrt(running_var + eps) + beta
+__global__ void __launch_bounds__(256)
+bn_frozen_kernel(int C, const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ conv_bias,
+                 const float *__restrict__ running_mean, const float *__restrict__ running_var, float eps,
+                 float *__restrict__ scale, float *__restrict__ shift, float *__restrict__ mean_out,
+                 float *__restrict__ invstd_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float invstd = 1.f / sqrtf(running_var[c] + eps);
+    const float mu = running_mean[c] - (conv_bias ? conv_bias[c] : 0.f);
+    const float sc = (gamma ? gamma[c] : 1.f) * invstd;
+    scale[c] = sc;
+    shift[c] = (beta ? beta[c] : 0.f) - mu * sc;
+    if (mean_out) mean_out[c] = mu;
+    if (invstd_out) invstd_out[c] = invstd;
 }
 
 // y = act(x * scale[c] + shift[c]) + r1 + r2   (NHWC half, 8 channels per lane)
@@ -262,10 +283,25 @@ extern "C" int ir2rgb_bn_finalize(const float *stats_partial, int rows, int C, l
                                   const float *beta, float *running_mean, float *running_var, float momentum,
                                   float eps, float *scale, float *shift, float *mean_out, float *invstd_out,
                                   int stat_updates, void *stream) {
-    if (rows < 1 || C < 1 || count < 1 || !stats_partial || !scale || !shift || stat_updates < 1) return IR2RGB_EINVAL;
+    return ir2rgb_bn_finalize_ex(stats_partial, rows, C, count, gamma, beta, nullptr, running_mean, running_var, momentum,
+                                 eps, scale, shift, mean_out, invstd_out, stat_updates, 0, stream);
+}
+
+extern "C" int ir2rgb_bn_finalize_ex(const float *stats_partial, int rows, int C, long count, const float *gamma,
+                                     const float *beta, const float *conv_bias, float *running_mean,
+                                     float *running_var, float momentum, float eps, float *scale, float *shift,
+                                     float *mean_out, float *invstd_out, int stat_updates, int frozen, void *stream) {
+    if (C < 1 || !scale || !shift) return IR2RGB_EINVAL;
+    if (frozen) {
+        if (!running_mean || !running_var) return IR2RGB_EINVAL;
+        bn_frozen_kernel<<<cdiv(C, 256), 256, 0, as_stream(stream)>>>(C, gamma, beta, conv_bias, running_mean, running_var,
+                                                                      eps, scale, shift, mean_out, invstd_out);
+        return ir2rgb_launch_status();
+    }
+    if (rows < 1 || count < 1 || !stats_partial || stat_updates < 1) return IR2RGB_EINVAL;
     bn_finalize_kernel<<<cdiv(C, 32), 1024, 0, as_stream(stream)>>>(stats_partial, rows, C, (double)count, gamma, beta,
-                                                                    running_mean, running_var, momentum, eps, scale,
-                                                                    shift, mean_out, invstd_out, stat_updates);
+                                                                    conv_bias, running_mean, running_var, momentum, eps,
+                                                                    scale, shift, mean_out, invstd_out, stat_updates);
     return ir2rgb_launch_status();
 }
 

@@ -113,22 +113,33 @@ def repeated_forward(times):
         _STAT_UPDATES = old
 
 
-def bn_finalize(stats, count, bn, training=True):
-    """-> (scale, shift, mean, invstd) fp32 [C].  Updates bn.running_* like nn.BatchNorm2d."""
-    rows, _, ch = stats.shape
-    dev = stats.device
+def bn_frozen(bn, training):
+    """True when nn.BatchNorm2d would normalise with its running statistics (module.eval() and tracked stats)."""
+    return (not training) and bn.track_running_stats and bn.running_mean is not None
+
+
+def bn_finalize(stats, count, bn, training=True, conv_bias=None):
+    """-> (scale, shift, mean, invstd) fp32 [C] for an input that does NOT carry ``conv_bias`` (the bias of the
+    convolution in front; BatchNorm cancels it, see ir2rgb_bn_finalize_ex).  Training mode: batch statistics
+    from the convolution's partial sums, running statistics updated like nn.BatchNorm2d.  Evaluation mode
+    (``training=False`` with tracked statistics): the running statistics, nothing updated; ``stats`` may be None."""
+    frozen = bn_frozen(bn, training)
+    ch = bn.num_features
+    dev = bn.weight.device if bn.weight is not None else stats.device
+    rows = 0 if stats is None else stats.shape[0]
     scale = torch.empty(ch, dtype=torch.float32, device=dev)
     shift = torch.empty_like(scale)
     mean = torch.empty_like(scale)
     invstd = torch.empty_like(scale)
     track = training and bn.track_running_stats and bn.running_mean is not None
     momentum = 0.1 if bn.momentum is None else bn.momentum
-    with _lib.on_device(stats):
-        rc = _lib.lib().ir2rgb_bn_finalize(_p(stats), rows, ch, int(count), _p(bn.weight), _p(bn.bias),
-                                           _p(bn.running_mean) if track else _p(None),
-                                           _p(bn.running_var) if track else _p(None), float(momentum), float(bn.eps),
-                                           _p(scale), _p(shift), _p(mean), _p(invstd), _STAT_UPDATES,
-                                           _lib.current_stream(stats))
+    use_running = track or frozen
+    with _lib.on_device(scale):
+        rc = _lib.lib().ir2rgb_bn_finalize_ex(_p(stats), rows, ch, int(count), _p(bn.weight), _p(bn.bias), _p(conv_bias),
+                                              _p(bn.running_mean) if use_running else _p(None),
+                                              _p(bn.running_var) if use_running else _p(None), float(momentum),
+                                              float(bn.eps), _p(scale), _p(shift), _p(mean), _p(invstd), _STAT_UPDATES,
+                                              int(frozen), _lib.current_stream(scale))
     _lib.check(rc, "bn_finalize")
     if track and bn.num_batches_tracked is not None:
         _PENDING_COUNTERS.append((bn.num_batches_tracked, _STAT_UPDATES))
@@ -234,10 +245,10 @@ def conv_stage(x, conv, bn, act, pad_mode, *, stride=None, pad=None, transposed=
     desc = C.make_desc(tuple(x.shape), conv.out_channels, conv.kernel_size, stride, pad, pad_mode, x.dtype, transposed,
                        output_padding, act=1 if fused_leaky else 0)
     wp = packed_weight(conv, desc)
-    y, stats = C.conv2d_fwd(desc, x, wp, conv.bias, want_stats=bn is not None)
     if bn is None:
-        return y
-    scale, shift, _, _ = bn_finalize(stats, desc.N * desc.Hout * desc.Wout, bn, training)
+        return C.conv2d_fwd(desc, x, wp, conv.bias)[0]
+    y, stats = C.conv2d_fwd(desc, x, wp, None, want_stats=not bn_frozen(bn, training))
+    scale, shift, _, _ = bn_finalize(stats, desc.N * desc.Hout * desc.Wout, bn, training, conv.bias)
     return bn_apply(y, scale, shift, act, res1, res2, out=y)
 
 
@@ -254,10 +265,10 @@ def first_stage(x_nchw, conv, bn, act, pad_mode, dtype, *, fused_leaky=False, tr
     desc = C.make_desc(tuple(xe.shape), conv.out_channels, (kh, 1), (sh, 1), (ph, 0), pad_mode, dtype,
                        act=1 if fused_leaky else 0)
     wp = packed_weight(conv, desc, _xexpanded_weight(kw), tag="xexp")
-    y, stats = C.conv2d_fwd(desc, xe, wp, conv.bias, want_stats=bn is not None)
     if bn is None:
-        return y
-    scale, shift, _, _ = bn_finalize(stats, desc.N * desc.Hout * desc.Wout, bn, training)
+        return C.conv2d_fwd(desc, xe, wp, conv.bias)[0]
+    y, stats = C.conv2d_fwd(desc, xe, wp, None, want_stats=not bn_frozen(bn, training))
+    scale, shift, _, _ = bn_finalize(stats, desc.N * desc.Hout * desc.Wout, bn, training, conv.bias)
     return bn_apply(y, scale, shift, act, out=y)
 
 

@@ -1,29 +1,33 @@
-"""GPU gradient parity: loss.backward() through the HIP stages vs torch autograd through the
-plain-torch fp32 restatement (oracle/networks_oracle.py, itself pinned to the reference goldens).
+"""Whole-network forward + backward parity of the HIP stages against the ROUNDING-EMULATING oracle
+(oracle/emulated.py: the reference's graph, fp32 torch operators and torch.autograd derivatives, values rounded to the
+compute dtype exactly where the HIP path stores a half tensor).  What remains between the two is summation order, so
+the bounds below are tight enough to catch a missing or mis-scaled term -- unlike a comparison of a half-precision
+network with an fp32 one, which can only be held to a rounding-noise bound (0.25 in round 1).  Per tensor, relative L2:
 
-Both sides start from the same seeded parameters and inputs.  Exactness of every stage's backward is
-established one stage deep in tests/test_stage_backward_gpu.py (<= 6e-3 f16 / 3e-2 bf16 against fp32
-autograd).  Here whole networks are chained: 12..40 half-precision layers whose BatchNorm statistics
-come from as few as 32 pixels and whose ReLU masks flip under rounding, so the bound is a noise
-bound, per parameter tensor, relative L2 (measured worst cases in parentheses):
-    local generator   f16 <= 1e-1 (6.1e-2)    bf16 <= 2.5e-1 (1.5e-1)
-    discriminator     f16 <= 6e-2 (3.4e-2)    bf16 <= 2e-1   (1.0e-1)
-    coarse generator  f16 <= 2.5e-1 (1.2e-1)
-Tensors whose oracle gradient is numerically zero (conv biases in front of BatchNorm) are skipped.
+    forward outputs              <= 5e-3
+    parameter / input gradients  <= 3e-2      (measured values are printed)
+
+The fp32 side of the story (same graph as the reference) is tests/test_networks_gpu.py (forward, reference goldens) and
+tests/test_harness_gpu.py (losses, gradients and whole training windows against reference-generated goldens).
+
+The flow head is scaled to emit flows of a few pixels (x0.05 on both sides): with random-init weights it emits +-40 px,
+and the warp's derivative w.r.t. the flow is piecewise constant per pixel cell, so at that magnitude a 1e-3 relative
+difference in the flow flips cells and the comparison would measure that, not the kernels.
 """
 import copy
 
-import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
 OPT = dict(gen_blocks=9, n_blocks_local=3, fg=False, no_flow=False, n_local_enhancers=1, feat_num=3)
+FWD_TOL, GRAD_TOL = 5e-3, 3e-2
 
 
 def _rel(a, b):
-    return ((a.float().cpu() - b).norm() / b.norm().clamp_min(1e-20)).item()
+    b = b.detach().float().cpu()
+    return ((a.detach().float().cpu() - b).norm() / b.norm().clamp_min(1e-20)).item()
 
 
 def _smooth(shape, seed):
@@ -34,112 +38,106 @@ def _smooth(shape, seed):
 
 
 def _tame_flow(g):
-    """Random-init flow heads emit +-20..40 px flows; the warp's gradient w.r.t. the flow is piecewise
-    constant per pixel cell, so at that magnitude half-precision rounding of the flow flips cells and
-    the comparison measures chaos, not kernels.  Scale the head down to sub-pixel flows (what a trained
-    network produces on slow motion) in BOTH modules."""
     with torch.no_grad():
-        g.model_final_flow[1].weight.mul_(0.01)
-        g.model_final_flow[1].bias.mul_(0.01)
+        g.model_final_flow[1].weight.mul_(0.05)
+        g.model_final_flow[1].bias.mul_(0.05)
 
 
-def _compare_grads(hip_mod, ref_mod, tol, skip_tiny=1e-7):
-    bad, worst = {}, 0.0
+def _compare_grads(hip_mod, ref_mod, tol, what):
     ref_norms = {k: p.grad.norm().item() for k, p in ref_mod.named_parameters() if p.grad is not None}
     scale = max(ref_norms.values())
+    errs = {}
     for (k, p), (_, q) in zip(hip_mod.named_parameters(), ref_mod.named_parameters()):
-        assert q.grad is not None, k
-        if q.grad.norm().item() < skip_tiny * scale:
-            continue  # analytically zero (bias before BatchNorm)
+        if q.grad is None or q.grad.norm().item() < 1e-6 * scale:
+            # the bias of a convolution in front of BatchNorm: exactly zero on the HIP side (None or zeros)
+            assert p.grad is None or p.grad.norm().item() <= 1e-4 * scale, k
+            continue
         assert p.grad is not None, f"no gradient for {k}"
-        e = _rel(p.grad, q.grad)
-        worst = max(worst, e)
-        if not e <= tol:
-            bad[k] = e
-    assert not bad, f"gradient relative L2 over {tol}: {dict(sorted(bad.items(), key=lambda kv: -kv[1])[:10])} ... worst {worst}, n_bad {len(bad)}"
-    return worst
+        errs[k] = _rel(p.grad, q.grad)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    print(what, "parameter gradients: worst", [(k, round(v, 4)) for k, v in worst], "of", len(errs))
+    bad = {k: v for k, v in errs.items() if not v <= tol}
+    assert not bad, f"{what}: gradient relative L2 over {tol}: {dict(sorted(bad.items(), key=lambda kv: -kv[1])[:10])}"
+    return max(errs.values())
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float16, 1e-1), (torch.bfloat16, 2.5e-1)])
-def test_local_generator_gradients(dev, dtype, tol):
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("model", ["composite", "composite-local"])
+def test_generator_forward_backward_vs_emulated(dev, model, dtype):
     from ir2rgb_amd import networks as N
-    from oracle import networks_oracle as NO
-    torch.manual_seed(21)
-    g = N.build_generator_module(9, 3, 6, 64, "composite-local", 3, "batch", 1, **OPT).train()
+    from oracle import emulated as E
+    local = model == "composite-local"
+    torch.manual_seed(21 if local else 23)
+    g = N.build_generator_module(9, 3, 6, 64, model, 3, "batch", 1 if local else 0, **OPT).train()
     _tame_flow(g)
     ref = copy.deepcopy(g)
-    A, P = _smooth((1, 9, 32, 48), 1), _smooth((1, 6, 32, 48), 2)
-    fi, ff = _smooth((1, 128, 16, 24), 3).abs(), _smooth((1, 128, 16, 24), 4).abs()
-    proj = [_smooth((1, c, 32, 48), 10 + c) for c in (3, 2, 1, 3)]
+    H, W = (32, 48) if local else (32, 64)
+    A, P = _smooth((1, 9, H, W), 1), _smooth((1, 6, H, W), 2)
+    fi = ff = None
+    if local:
+        fi, ff = _smooth((1, 128, H // 2, W // 2), 3).abs(), _smooth((1, 128, H // 2, W // 2), 4).abs()
+    proj = [_smooth((1, c, H, W), 10 + c) for c in (3, 2, 1, 3)]
 
     def loss_of(outs):
         final, flow, weight, raw = outs[0], outs[1], outs[2], outs[3]
-        return ((final * proj[0].to(final.device)).sum() + (flow * proj[1].to(final.device)).sum() * 0.05 +
-                (weight * proj[2].to(final.device)).sum() + (raw * proj[3].to(final.device)).sum())
+        dv = final.device
+        return ((final * proj[0].to(dv)).sum() + (flow * proj[1].to(dv)).sum() * 0.05 + (weight * proj[2].to(dv)).sum() +
+                (raw * proj[3].to(dv)).sum())
 
-    fir = fi.clone().requires_grad_()
-    loss_ref = loss_of(NO.generator_forward(ref, A, P, fir, ff))
-    loss_ref.backward()
+    fir = fi.clone().requires_grad_() if local else None
+    out_ref = E.generator_forward(ref, A, P, fir, ff, dtype=dtype)
+    loss_of(out_ref).backward()
 
     g = g.to(dev)
     g.compute_dtype = dtype
-    fih = fi.to(dev).requires_grad_()
-    loss_hip = loss_of(g(A.to(dev), P.to(dev), None, fih, ff.to(dev), None, False))
-    loss_hip.backward()
-    assert abs(loss_hip.item() - loss_ref.item()) <= tol * abs(loss_ref.item()) + 1.0
-    worst = _compare_grads(g, ref, tol)
-    e_in = _rel(fih.grad, fir.grad)
-    print(f"local generator {dtype}: worst param-grad rel L2 {worst:.4f}, coarse-feature grad {e_in:.4f}")
-    assert e_in <= tol
+    fih = fi.to(dev).requires_grad_() if local else None
+    out = g(A.to(dev), P.to(dev), None, fih, ff.to(dev) if local else None, None, False)
+    loss_of(out).backward()
+    ferr = {n: _rel(out[i], out_ref[i]) for i, n in ((0, "img_final"), (1, "flow"), (2, "weight"), (3, "img_raw"), (4, "img_feat"),
+                                                     (5, "flow_feat"))}
+    print(model, dtype, "forward", {k: round(v, 5) for k, v in ferr.items()})
+    assert all(v <= FWD_TOL for v in ferr.values()), ferr
+    _compare_grads(g, ref, GRAD_TOL, f"{model} {dtype}")
+    if local:
+        e_in = _rel(fih.grad, fir.grad)
+        print(model, dtype, "coarse-feature gradient", e_in)
+        assert e_in <= GRAD_TOL
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float16, 6e-2), (torch.bfloat16, 2e-1)])
-def test_discriminator_gradients(dev, dtype, tol):
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("input_nc", [6, 13])
+def test_discriminator_forward_backward_vs_emulated(dev, input_nc, dtype):
     from ir2rgb_amd import networks as N
-    from oracle import networks_oracle as NO
+    from ir2rgb_amd.losses import fused_losses
+    from oracle import emulated as E
     torch.manual_seed(22)
-    d = N.build_discriminator_module(6, 64, 3, "batch", 2, True).train()
+    d = N.build_discriminator_module(input_nc, 64, 3, "batch", 2, True).train()
     ref = copy.deepcopy(d)
-    x = _smooth((2, 6, 48, 64), 5)
+    x, x2 = _smooth((2, input_nc, 48, 64), 5), _smooth((2, input_nc, 48, 64), 6)
 
-    def loss_of(outs):
-        # LSGAN-style on the logits plus a feature term on every intermediate (as GAN_and_FM_loss does)
-        total = 0
-        for sc in outs:
-            total = total + ((sc[-1].float() - 1) ** 2).mean()
-            for f in sc[:-1]:
-                total = total + f.float().abs().mean() * 0.1
-        return total
-
+    # LSGAN term on the logits + feature matching against a second (constant) input, as GAN_and_FM_loss composes them
     xr = x.clone().requires_grad_()
-    loss_of(NO.discriminator_forward(ref, xr)).backward()
+    fr, cr = E.discriminator_forward(ref, xr, dtype), E.discriminator_forward(ref, x2, dtype)
+    loss_ref = sum(((sc[-1] - 1) ** 2).mean() for sc in fr)
+    for i in range(2):
+        for j in range(4):
+            loss_ref = loss_ref + E.l1_half(fr[i][j], cr[i][j], 0.5 * 0.8 * 10.0, dtype)
+    loss_ref.backward()
+
     d = d.to(dev)
     d.compute_dtype = dtype
     xh = x.to(dev).requires_grad_()
-    loss_of(d(xh)).backward()
-    worst = _compare_grads(d, ref, tol)
+    fh, ch = d(xh), d(x2.to(dev))
+    terms = [("mse", sc[-1], 1.0, 1.0, 0) for sc in fh]
+    terms += [("l1", fh[i][j], ch[i][j], 0.5 * 0.8 * 10.0, 0) for i in range(2) for j in range(4)]
+    loss = fused_losses(terms, 1, dtype)[0]
+    loss.backward()
+    ferr = {f"out{i}_{j}": _rel(fh[i][j], fr[i][j]) for i in range(2) for j in range(5)}
+    print("discriminator", input_nc, dtype, "forward", {k: round(v, 5) for k, v in ferr.items()},
+          "loss", loss.item(), loss_ref.item())
+    assert all(v <= FWD_TOL for v in ferr.values()), ferr
+    assert abs(loss.item() - loss_ref.item()) <= 2e-3 * abs(loss_ref.item())
+    _compare_grads(d, ref, GRAD_TOL, f"discriminator {input_nc} {dtype}")
     e_in = _rel(xh.grad, xr.grad)
-    print(f"discriminator {dtype}: worst param-grad rel L2 {worst:.4f}, input grad {e_in:.4f}")
-    assert e_in <= tol
-
-
-def test_composite_generator_gradients_f16(dev):
-    """Coarse generator (encoders, 9 ResnetBlocks, transposed convolutions) at ngf=64."""
-    from ir2rgb_amd import networks as N
-    from oracle import networks_oracle as NO
-    torch.manual_seed(23)
-    g = N.build_generator_module(9, 3, 6, 64, "composite", 3, "batch", 0, **OPT).train()
-    _tame_flow(g)
-    ref = copy.deepcopy(g)
-    A, P = _smooth((1, 9, 32, 64), 1), _smooth((1, 6, 32, 64), 2)
-    pr = _smooth((1, 3, 32, 64), 7)
-
-    def loss_of(outs):
-        return (outs[0] * pr.to(outs[0].device)).sum() + (outs[1] ** 2).mean() * 0.01 + outs[2].sum() * 0.01
-
-    loss_of(NO.generator_forward(ref, A, P)).backward()
-    g = g.to(dev)
-    g.compute_dtype = torch.float16
-    loss_of(g(A.to(dev), P.to(dev), None, None, None, None, False)).backward()
-    worst = _compare_grads(g, ref, 2.5e-1)
-    print(f"composite generator f16: worst param-grad rel L2 {worst:.4f}")
+    print("discriminator", input_nc, dtype, "input gradient", e_in)
+    assert e_in <= GRAD_TOL

@@ -152,3 +152,71 @@ def test_layout_roundtrip_and_xexpand(dev):
         for kx in (0, 3, 6):
             assert torch.equal(e[0, ci * 7 + kx], pad[0, ci, :, kx:kx + 11].bfloat16().float())
     assert e[0, 63].abs().max() == 0
+
+
+def _randomize_running_stats(m, seed):
+    g = torch.Generator().manual_seed(seed)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.copy_(torch.randn(mod.num_features, generator=g) * 0.05)
+            mod.running_var.copy_(torch.rand(mod.num_features, generator=g) + 0.5)
+
+
+def test_generator_eval_mode_uses_running_statistics(dev, golden_dir):
+    """module.eval(): nn.BatchNorm2d normalises with running_mean / running_var and updates nothing (the reference's
+    test_vid2vid.py path).  Checked against the plain-torch restatement (oracle/networks_oracle.py, pinned by the
+    reference goldens in train mode) evaluated in eval mode on a CPU copy of the same containers; f16, relative L2 <= 5e-3."""
+    import copy
+    from oracle.networks_oracle import generator_forward
+    g = np.load(os.path.join(golden_dir, "net_G0_ngf64_32x64.npz"))
+    m = _gen(g, dev, torch.float16)
+    _randomize_running_stats(m, 5)
+    m.eval()
+    ref = copy.deepcopy(m).cpu().eval()
+    A, prev = torch.from_numpy(g["A"]), torch.from_numpy(g["prev"])
+    before = {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "tracked" in k}
+    with torch.no_grad():
+        out = m(A.to(dev), prev.to(dev), None, None, None, None, False)
+        want = generator_forward(ref, A, prev)
+    errs = {n: rel_l2(out[i], want[i].numpy()) for i, n in ((1, "flow"), (2, "weight"), (3, "img_raw"), (4, "img_feat"))}
+    print("eval-mode generator", errs)
+    assert all(v <= 5e-3 for v in errs.values()), errs
+    after = m.state_dict()
+    assert all(torch.equal(after[k], v) for k, v in before.items()), "eval mode must not touch the running statistics"
+    # and the batch statistics really are not what is used: the train-mode result differs
+    m.train()
+    with torch.no_grad():
+        out_t = m(A.to(dev), prev.to(dev), None, None, None, None, False)
+    assert rel_l2(out_t[3], want[3].numpy()) > 5e-2
+
+
+def test_discriminator_eval_mode_forward_and_backward(dev, golden_dir):
+    """Evaluation-mode BatchNorm is an affine map: forward against the oracle in eval mode, and the gradients of a scalar
+    of the logits w.r.t. the input and every parameter (the convolution biases in front of BatchNorm included, which have
+    zero gradient in train mode and a non-zero one here) against torch autograd of the oracle."""
+    import copy
+    from ir2rgb_amd import networks as N
+    from oracle.networks_oracle import discriminator_forward
+    g = np.load(os.path.join(golden_dir, "net_D_nc6_64x96.npz"))
+    torch.manual_seed(int(g["seed"]))
+    d = N.build_discriminator_module(6, 64, 3, "batch", 2, True).to(dev)
+    d.compute_dtype = torch.float16
+    _randomize_running_stats(d, 6)
+    d.eval()
+    ref = copy.deepcopy(d).cpu().eval()
+    x = torch.from_numpy(g["x"])
+    xg = x.to(dev).requires_grad_()
+    out = d(xg)
+    xr = x.clone().requires_grad_()
+    want = discriminator_forward(ref, xr)
+    errs = {f"out{i}_{j}": rel_l2(o, want[i][j].detach().numpy()) for i, sc in enumerate(out) for j, o in enumerate(sc)}
+    print("eval-mode discriminator", errs)
+    assert all(v <= 5e-3 for v in errs.values()), errs
+    sum((sc[-1].float() ** 2).mean() for sc in out).backward()
+    sum((sc[-1] ** 2).mean() for sc in want).backward()
+    gerr = {"x": rel_l2(xg.grad, xr.grad.numpy())}
+    pr = dict(ref.named_parameters())
+    for k, p in d.named_parameters():
+        gerr[k] = rel_l2(p.grad, pr[k].grad.numpy())
+    print("eval-mode discriminator gradients", {k: round(v, 4) for k, v in gerr.items()})
+    assert all(v <= 2e-2 for v in gerr.values()), gerr
