@@ -112,6 +112,74 @@ def _compose(f, g):
     return lambda w: g(f(w))
 
 
+# ---------------------------------------------------------------------------------------------
+# channel padding: any ngf / ndf behind the reference's factories (networks.py:51-82; generator.py:36 halves ngf per
+# spatial scale).  The MFMA kernels want 64-multiples (BatchNorm backward: powers of two), so a layer whose width is not
+# one runs at the next power of two >= 64: zero weight rows / columns, zero BatchNorm shift for the extra channels, which
+# therefore stay exactly zero through convolution, BatchNorm (0 * scale + 0), ReLU and residual adds, forward and backward.
+# Parameters and their gradients keep the reference's shapes.  Widths that are 64-multiples take none of this.
+# ---------------------------------------------------------------------------------------------
+def padded_width(c):
+    return c if c % 64 == 0 and (c & (c - 1)) == 0 else max(64, 1 << (c - 1).bit_length())
+
+
+def _pad_dim(t, dim, to, value=0.0):
+    if t.shape[dim] == to:
+        return t
+    shape = list(t.shape)
+    shape[dim] = to - t.shape[dim]
+    return torch.cat([t, t.new_full(shape, value)], dim)
+
+
+def _pad_weight_fn(cout_to, cin_to, transposed):
+    """Conv2d weight [Cout,Cin,kh,kw] (ConvTranspose2d: [Cin,Cout,kh,kw]) -> zero-padded to the widths the kernels run at."""
+    def f(w):
+        a, b = (cin_to, cout_to) if transposed else (cout_to, cin_to)
+        return _pad_dim(_pad_dim(w, 0, a), 1, b)
+    return f
+
+
+class PadChannelsFn(Function):
+    """[N,C,H,W] half -> [N,Cp,H,W] channels_last half with zero extra channels (a tensor entering the padded domain from
+    outside: coarse features, a stand-alone ResnetBlock call); the gradient is the slice."""
+
+    @staticmethod
+    def forward(ctx, x, cp):
+        ctx.c = x.shape[1]
+        out = torch.zeros((x.shape[0], cp, x.shape[2], x.shape[3]), dtype=x.dtype, device=x.device).contiguous(
+            memory_format=torch.channels_last)
+        out[:, :ctx.c] = x
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, :ctx.c], None
+
+
+def pad_channels(x, cp):
+    return x if x.shape[1] == cp else PadChannelsFn.apply(x, cp)
+
+
+class _PaddedBN:
+    """nn.BatchNorm2d seen at a padded width by bn_finalize: gamma 1 / beta 0 / running (0, 1) for the extra channels;
+    ``commit`` writes the real channels' running statistics back."""
+
+    def __init__(self, bn, cp):
+        self.bn, self.num_features = bn, cp
+        self.weight = _pad_dim(bn.weight.detach(), 0, cp, 1.0)
+        self.bias = _pad_dim(bn.bias.detach(), 0, cp, 0.0)
+        self.track_running_stats, self.momentum, self.eps = bn.track_running_stats, bn.momentum, bn.eps
+        self.running_mean = None if bn.running_mean is None else _pad_dim(bn.running_mean, 0, cp, 0.0)
+        self.running_var = None if bn.running_var is None else _pad_dim(bn.running_var, 0, cp, 1.0)
+        self.num_batches_tracked = bn.num_batches_tracked
+
+    def commit(self, training):
+        if training and self.track_running_stats and self.running_mean is not None:
+            c = self.bn.num_features
+            self.bn.running_mean.copy_(self.running_mean[:c])
+            self.bn.running_var.copy_(self.running_var[:c])
+
+
 def conv_dgrad(gy, conv, spec, x_shape, weight_fn=None, tag="dgrad"):
     """gy: grad wrt the convolution output (channels_last half, channels % 64 == 0).  ``weight_fn``
     maps conv.weight to the weight tensor the forward convolution actually used (x-expanded / padded
@@ -292,18 +360,27 @@ class ConvStageFn(Function):
     def forward(ctx, x, weight, bias, gamma, beta, res1, res2, spec, conv, bn):
         dt = spec["dtype"]
         first = spec["first"]
+        cout, cin = conv.out_channels, conv.in_channels
+        cout_p = cout if spec.get("out_f32", False) else padded_width(cout)
+        cin_p = cin if first else padded_width(cin)
+        padded = cout_p != cout or cin_p != cin
+        ctx.wfn = wfn = _pad_weight_fn(cout_p, cin_p, spec["transposed"]) if padded else None
         if first:
             kh, kw = conv.kernel_size
             xin = L.xexpand(x, kw, spec["stride"][1], spec["pad"][1], spec["pad_mode"], dt)
-            desc = C.make_desc(tuple(xin.shape), conv.out_channels, (kh, 1), (spec["stride"][0], 1), (spec["pad"][0], 0),
+            desc = C.make_desc(tuple(xin.shape), cout_p, (kh, 1), (spec["stride"][0], 1), (spec["pad"][0], 0),
                                spec["pad_mode"], dt, act=_fused_act(spec))
-            wp = L.packed_weight(conv, desc, L._xexpanded_weight(kw), tag="xexp")
+            wp = L.packed_weight(conv, desc, _compose(wfn, L._xexpanded_weight(kw)), tag="xexp")
         else:
+            if x.shape[1] != cin_p:
+                raise ValueError(f"conv stage: input has {x.shape[1]} channels, the layer runs at {cin_p} (autograd.pad_channels)")
             xin = x
-            desc = C.make_desc(tuple(x.shape), conv.out_channels, spec["k"], spec["stride"], spec["pad"], spec["pad_mode"],
+            desc = C.make_desc(tuple(x.shape), cout_p, spec["k"], spec["stride"], spec["pad"], spec["pad_mode"],
                                dt, spec["transposed"], spec.get("output_padding", 0), act=_fused_act(spec),
                                out_f32=spec.get("out_f32", False))
-            wp = L.packed_weight(conv, desc)
+            wp = L.packed_weight(conv, desc, wfn, tag="wpad" if padded else "w")
+        if padded and bias is not None:
+            bias = _pad_dim(bias.detach(), 0, cout_p)
         scale = shift = mean = invstd = None
         ctx.frozen = False
         if bn is not None:
@@ -311,7 +388,10 @@ class ConvStageFn(Function):
             # handed to the statistics kernel, which needs it for the running mean only (ir2rgb_bn_finalize_ex)
             ctx.frozen = L.bn_frozen(bn, spec["training"])
             y, stats = C.conv2d_fwd(desc, xin, wp, None, want_stats=not ctx.frozen)
-            scale, shift, mean, invstd = L.bn_finalize(stats, desc.N * desc.Hout * desc.Wout, bn, spec["training"], bias)
+            bnp = _PaddedBN(bn, cout_p) if cout_p != cout else bn
+            scale, shift, mean, invstd = L.bn_finalize(stats, desc.N * desc.Hout * desc.Wout, bnp, spec["training"], bias)
+            if bnp is not bn:
+                bnp.commit(spec["training"])
             z = L.bn_apply(y, scale, shift, spec["act"], res1, res2)
         else:
             y, _ = C.conv2d_fwd(desc, xin, wp, bias)
@@ -328,7 +408,8 @@ class ConvStageFn(Function):
         spec, conv = ctx.spec, ctx.conv
         xin, y, scale, shift, mean, invstd = ctx.saved_tensors
         hdt = xin.dtype
-        pad_fn = None
+        pad_fn = wfn = ctx.wfn
+        cout, cin = conv.out_channels, conv.in_channels
         flags = getattr(conv, "_ir2rgb_bwd", 0)
         want_params = not (flags & SKIP_PARAM_GRADS)
         want_dx = ctx.needs_input_grad[0] and not (spec["first"] and (flags & SKIP_INPUT_GRAD))
@@ -336,7 +417,7 @@ class ConvStageFn(Function):
             # thin fp32 output (PatchGAN logits): pad the gradient to 64 channels for the MFMA adjoint
             cout = y.shape[1]
             gy, gy_thin, dbias = thin_grad_expand(gz, hdt)      # 64-channel / 8-channel zero-padded halves, sum
-            pad_fn = lambda w: torch.cat([w, w.new_zeros((64 - w.shape[0],) + tuple(w.shape[1:]))], 0)  # noqa: E731
+            pad_fn = _compose(wfn, lambda w: torch.cat([w, w.new_zeros((64 - w.shape[0],) + tuple(w.shape[1:]))], 0))
             dgamma = dbeta = None
         elif ctx.has_bn:
             gz = _as_half_nhwc(gz, hdt)
@@ -361,7 +442,7 @@ class ConvStageFn(Function):
                     raise NotImplementedError("input gradient of a reflect-padded first layer is never needed")
                 # adjoint of the (kh x 1) convolution over the expanded image, then of the x-im2col
                 n, _, h, wout = xin.shape
-                dxe = conv_dgrad(gy, conv, sub, (n, 64, h, wout), L._xexpanded_weight(kw), tag="dgrad_xexp")
+                dxe = conv_dgrad(gy, conv, sub, (n, 64, h, wout), _compose(wfn, L._xexpanded_weight(kw)), tag="dgrad_xexp")
                 dx = xexpand_bwd(dxe, ctx.x_shape[1], ctx.x_shape[3], kw, spec["stride"][1], spec["pad"][1],
                                  spec["pad_mode"])
             else:
@@ -375,9 +456,8 @@ class ConvStageFn(Function):
                 def first_wgrad():
                     kh, kw = conv.kernel_size
                     sub = dict(spec, k=(kh, 1), stride=(spec["stride"][0], 1), pad=(spec["pad"][0], 0))
-                    gwe = conv_wgrad(xin, gy, (conv.out_channels, 64, kh, 1), sub)      # [co][64][kh][1]
-                    cin = conv.in_channels
-                    gwe = gwe[:, :cin * kw, :, 0].reshape(conv.out_channels, cin, kw, kh)  # [co][ci][kx][ky]
+                    gwe = conv_wgrad(xin, gy, (gy.shape[1], 64, kh, 1), sub)            # [co_p][64][kh][1]
+                    gwe = gwe[:cout, :cin * kw, :, 0].reshape(cout, cin, kw, kh)        # [co][ci][kx][ky]
                     return gwe.permute(0, 1, 3, 2).contiguous()
                 dw = wgrad_overlapped(conv, first_wgrad, xin, gy)
             else:
@@ -385,10 +465,19 @@ class ConvStageFn(Function):
                     wsh = (8,) + tuple(conv.weight.shape[1:])
                     dw = wgrad_overlapped(conv, lambda: conv_wgrad(xin, gy, wsh, spec)[:conv.out_channels].contiguous(),
                                           xin, gy)
+                elif wfn is not None:   # the layer ran at padded widths: the parameter's gradient is the real corner
+                    def padded_wgrad():
+                        g = conv_wgrad(xin, gy, None, spec)
+                        return (g[:cin, :cout] if spec["transposed"] else g[:cout, :cin]).contiguous()
+                    dw = wgrad_overlapped(conv, padded_wgrad, xin, gy)
                 else:
                     dw = wgrad_overlapped(conv, lambda: conv_wgrad(xin, gy, tuple(conv.weight.shape), spec), xin, gy)
         r1 = gz if ctx.has_res[0] else None
         r2 = gz if ctx.has_res[1] else None
+        if wfn is not None:      # reference-shaped parameter gradients
+            dbias = dbias[:cout] if dbias is not None else None
+            dgamma = dgamma[:cout] if dgamma is not None else None
+            dbeta = dbeta[:cout] if dbeta is not None else None
         return dx, dw, (dbias if ctx.needs_input_grad[2] else None), dgamma, dbeta, r1, r2, None, None, None
 
 
@@ -446,20 +535,21 @@ class HeadFn(Function):
         gfeat = None
         if ctx.needs_input_grad[0]:
             holder = convs[0]
-            key = ("ysplit_adj", _DT[feat.dtype]) + tuple((c.weight._version, c.weight.data_ptr()) for c in convs)
+            key = ("ysplit_adj", _DT[feat.dtype], cin) + tuple((c.weight._version, c.weight.data_ptr()) for c in convs)
             cache = holder.__dict__.setdefault("_ir2rgb_packed", {})
             hit = cache.get("ysplit_adj")
             desc = C.make_desc((n, CT, h, w), cin, (1, kw), 1, (0, kw - 1), C.PAD_ZERO, feat.dtype)
             if hit is None or hit[0] != key:
                 with torch.no_grad():
-                    wcat = torch.cat([c.weight.detach().float() for c in convs], 0)
+                    wcat = _pad_dim(torch.cat([c.weight.detach().float() for c in convs], 0), 1, cin)
                     wy = _pad_rows(L._ysplit_weight(wcat), CT).contiguous()      # [64][cin][1][kw] forward weight
                     cache["ysplit_adj"] = (key, C.pack_weight(desc, wy, adjoint=True))
             dpad, _ = C.conv2d_fwd(desc, dT, cache["ysplit_adj"][1])
             gfeat = fold_reflect(dpad, 0, kw // 2)
         wdesc = C.make_desc(tuple(feat.shape), CT, (1, kw), 1, (0, kw // 2), C.PAD_REFLECT, feat.dtype)
         gw = C.conv2d_wgrad(wdesc, feat, dT)                                       # [64][cin][1][kw]
-        gw = gw[:cout * kh, :, 0, :].reshape(cout, kh, cin, kw).permute(0, 2, 1, 3).contiguous()   # [cout][cin][kh][kw]
+        gw = gw[:cout * kh, :, 0, :].reshape(cout, kh, cin, kw).permute(0, 2, 1, 3)                 # [cout][cin][kh][kw]
+        gw = gw[:, :convs[0].in_channels].contiguous()          # (a padded feature map: the real input channels)
         gws, gbs, o = [], [], 0
         for c in convs:
             gws.append(gw[o:o + c.out_channels])

@@ -286,12 +286,14 @@ def head_stage(feat, convs, acts, mul=1.0):
     desc = C.make_desc(tuple(feat.shape), (cout * kh + 7) // 8 * 8, (1, kw), 1, (0, kw // 2), C.PAD_REFLECT, feat.dtype,
                        out_f32=True)
     holder = convs[0]
-    key = ("ysplit", desc.dtype) + tuple((c.weight._version, c.weight.data_ptr()) for c in convs)
+    key = ("ysplit", desc.dtype, feat.shape[1]) + tuple((c.weight._version, c.weight.data_ptr()) for c in convs)
     cache = holder.__dict__.setdefault("_ir2rgb_packed", {})
     hit = cache.get("ysplit")
     if hit is None or hit[0] != key:
         with torch.no_grad():
             wcat = torch.cat([c.weight.detach().float() for c in convs], 0)
+            if wcat.shape[1] != feat.shape[1]:      # the feature map runs at a padded width (autograd.padded_width)
+                wcat = torch.cat([wcat, wcat.new_zeros((wcat.shape[0], feat.shape[1] - wcat.shape[1]) + tuple(wcat.shape[2:]))], 1)
             cache["ysplit"] = (key, C.pack_weight(desc, _ysplit_weight(wcat).contiguous()))
     wp = cache["ysplit"][1]
     t, _ = C.conv2d_fwd(desc, feat, wp, None, want_stats=False)

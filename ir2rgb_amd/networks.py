@@ -34,8 +34,8 @@ from . import conv as C
 from . import layers as L
 
 __all__ = ["build_generator_module", "build_discriminator_module", "get_grid", "weights_init", "get_norm_layer",
-           "CompositeGeneratorModule", "CompositeLocalGeneratorModule", "MultiScaleDiscriminator", "NLayerDiscriminator",
-           "ResnetBlock"]
+           "CompositeGeneratorModule", "CompositeLocalGeneratorModule", "GlobalGenerator", "MultiScaleDiscriminator",
+           "NLayerDiscriminator", "ResnetBlock"]
 
 
 # ---------------------------------------------------------------------------------------------
@@ -95,7 +95,7 @@ class ResnetBlock(nn.Module):
 
     def forward(self, x):
         dt = getattr(self, "compute_dtype", torch.bfloat16)
-        return self.run(A.to_nhwc_half(x, dt))
+        return _real(self.run(_padded(A.to_nhwc_half(x, dt))), x.shape[1])
 
 
 # ---------------------------------------------------------------------------------------------
@@ -146,9 +146,18 @@ def _up(nc_in, norm_layer):
             norm_layer(nc_in // 2), nn.ReLU(True)]
 
 
-def _check_ngf(ngf):
-    if ngf % 64:
-        raise NotImplementedError(f"ngf/ndf must be a multiple of 64 for the MFMA kernels (got {ngf})")
+def _padded(x):
+    """A half feature map entering the kernels' domain: widths that are not a power of two >= 64 are zero-padded to
+    the next one (autograd.padded_width); the usual widths pass through untouched."""
+    return A.pad_channels(x, A.padded_width(x.shape[1]))
+
+
+def _real(x, channels):
+    """The reference-shaped view of a feature map that ran at a padded width (a dense copy: the extra channels are
+    zero and callers expect [N, channels, H, W])."""
+    if x is None or x.shape[1] == channels:
+        return x
+    return x[:, :channels].contiguous(memory_format=torch.channels_last)
 
 
 class _CompositeBase(nn.Module):
@@ -180,8 +189,7 @@ class CompositeGeneratorModule(_CompositeBase):
         super().__init__()
         if use_fg_model:
             raise NotImplementedError("foreground model (fg=True) is a dead branch for IR->RGB")
-        _check_ngf(ngf)
-        self.use_fg_model, self.no_flow = False, no_flow
+        self.use_fg_model, self.no_flow, self.ngf = False, no_flow, ngf
         res = lambda: ResnetBlock(ngf * 2 ** n_downsampling, padding_type, norm_layer)  # noqa: E731
 
         # construction order == reference order: same RNG stream, same initial weights
@@ -223,7 +231,7 @@ class CompositeGeneratorModule(_CompositeBase):
             flow_feat = _run_sequence(self.model_up_flow, _run_sequence(self.model_res_flow, downsample, dt, tr), dt, tr)
         img_final, flow, weight, img_raw = self._heads_and_blend(img_feat, flow_feat, img_prev, use_raw_only, 20.0)
         L.flush_bn_counters()
-        return img_final, flow, weight, img_raw, img_feat, flow_feat, None
+        return img_final, flow, weight, img_raw, _real(img_feat, self.ngf), _real(flow_feat, self.ngf), None
 
 
 class CompositeLocalGeneratorModule(_CompositeBase):
@@ -234,8 +242,7 @@ class CompositeLocalGeneratorModule(_CompositeBase):
         super().__init__()
         if use_fg_model:
             raise NotImplementedError("foreground model (fg=True) is a dead branch for IR->RGB")
-        _check_ngf(ngf)
-        self.use_fg_model, self.no_flow, self.scale = False, no_flow, scale
+        self.use_fg_model, self.no_flow, self.scale, self.ngf = False, no_flow, scale, ngf
         down_seg = _first7(input_nc, ngf, norm_layer) + _down(ngf, norm_layer)
         down_img = _first7(prev_output_nc, ngf, norm_layer) + _down(ngf, norm_layer)
         up_img = [ResnetBlock(ngf * 2, padding_type, norm_layer) for _ in range(n_blocks_local)] + _up(ngf * 2, norm_layer)
@@ -264,16 +271,54 @@ class CompositeLocalGeneratorModule(_CompositeBase):
         dt, tr = self.compute_dtype, self.training
         seg = self._encode(self.model_down_seg, input, dt, tr)
         down_img = self._encode(self.model_down_img, img_prev, dt, tr, res1=seg)                   # (:290)
-        img_in = A.add(down_img, A.to_nhwc_half(img_feat_coarse, dt))                      # (:291)
+        img_in = A.add(down_img, _padded(A.to_nhwc_half(img_feat_coarse, dt)))             # (:291)
         img_feat = _run_sequence(self.model_up_img, img_in, dt, tr)
         flow_feat = None
         if not self.no_flow:
-            flow_in = A.add(down_img, A.to_nhwc_half(flow_feat_coarse, dt))                # (:297)
+            flow_in = A.add(down_img, _padded(A.to_nhwc_half(flow_feat_coarse, dt)))       # (:297)
             flow_feat = _run_sequence(self.model_up_flow, flow_in, dt, tr)
         img_final, flow, weight, img_raw = self._heads_and_blend(img_feat, flow_feat, img_prev, use_raw_only,
                                                                  20.0 * (2 ** self.scale))
         L.flush_bn_counters()
-        return img_final, flow, weight, img_raw, img_feat, flow_feat, None
+        return img_final, flow, weight, img_raw, _real(img_feat, self.ngf), _real(flow_feat, self.ngf), None
+
+
+class GlobalGenerator(nn.Module):
+    """pix2pixHD global generator (reference networks.py:320-352, factory name 'global'): one nn.Sequential ``model`` =
+    [ReflPad3, Conv7x7, norm, ReLU] + n_downsampling x [Conv3x3 s2, norm, ReLU] (channels capped at 1024) + n_blocks
+    ResnetBlocks + n_downsampling x [ConvT3x3 s2, norm, ReLU] + [ReflPad3, Conv7x7, Tanh].  HIP execution: the same
+    stage runner as the composite generators, the head as the separable 7x7 kernel with tanh."""
+    compute_dtype = torch.bfloat16
+
+    def __init__(self, input_nc, output_nc, ngf=64, n_downsampling=3, n_blocks=9, norm_layer=nn.BatchNorm2d,
+                 padding_type="reflect"):
+        assert n_blocks >= 0
+        super().__init__()
+        ch_max = 1024
+        model = _first7(input_nc, ngf, norm_layer)
+        for i in range(n_downsampling):
+            mult = 2 ** i
+            model += [nn.Conv2d(min(ch_max, ngf * mult), min(ch_max, ngf * mult * 2), kernel_size=3, stride=2, padding=1),
+                      norm_layer(min(ch_max, ngf * mult * 2)), nn.ReLU(True)]
+        mult = 2 ** n_downsampling
+        model += [ResnetBlock(min(ch_max, ngf * mult), padding_type, norm_layer) for _ in range(n_blocks)]
+        for i in range(n_downsampling):
+            mult = 2 ** (n_downsampling - i)
+            model += [nn.ConvTranspose2d(min(ch_max, ngf * mult), min(ch_max, int(ngf * mult / 2)), kernel_size=3, stride=2,
+                                         padding=1, output_padding=1), norm_layer(min(ch_max, int(ngf * mult / 2))), nn.ReLU(True)]
+        model += [nn.ReflectionPad2d(3), nn.Conv2d(ngf, output_nc, kernel_size=7, padding=0), nn.Tanh()]
+        self.model = _seq(model)
+
+    def forward(self, input, feat=None):
+        if feat is not None:
+            input = torch.cat([input, feat], dim=1)
+        if not input.is_cuda:
+            raise ValueError("ir2rgb_amd generators run on an AMD GPU only (no CPU fallback)")
+        mods = list(self.model)
+        x = _run_sequence(mods[:-3], input, self.compute_dtype, self.training)
+        out = A.head_stage(x, [mods[-2]], [1] * mods[-2].out_channels)
+        L.flush_bn_counters()
+        return out
 
 
 # ---------------------------------------------------------------------------------------------
@@ -285,7 +330,6 @@ class NLayerDiscriminator(nn.Module):
 
     def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer=nn.BatchNorm2d, getIntermFeat=False):
         super().__init__()
-        _check_ngf(ndf)
         self.getIntermFeat, self.n_layers = getIntermFeat, n_layers
         kw, padw = 4, 2
         groups = [[nn.Conv2d(input_nc, ndf, kernel_size=kw, stride=2, padding=padw), nn.LeakyReLU(0.2, True)]]
@@ -310,10 +354,10 @@ def _run_patchgan(groups, x_nchw, dtype, training):
     half; the last one -- the 1-channel logits -- as fp32)."""
     g0 = groups[0]
     h = A.conv_stage(x_nchw, g0[0], None, L.ACT_NONE, C.PAD_ZERO, dtype, first=True, fused_leaky=True, training=training)
-    outs = [h]
+    outs = [_real(h, g0[0].out_channels)]
     for g in groups[1:-1]:
         h = A.conv_stage(h, g[0], g[1], L.ACT_LEAKY, C.PAD_ZERO, dtype, training=training)
-        outs.append(h)
+        outs.append(_real(h, g[0].out_channels))
     outs.append(A.conv_stage(h, groups[-1][0], None, L.ACT_NONE, C.PAD_ZERO, dtype, out_f32=True, training=training))
     return outs
 
@@ -375,7 +419,9 @@ def build_generator_module(input_nc, output_nc, prev_output_nc, ngf, model_name,
         generator = CompositeLocalGeneratorModule(input_nc, output_nc, prev_output_nc, ngf, n_downsampling,
                                                   opt["n_blocks_local"], opt["fg"], opt["no_flow"], norm_layer,
                                                   scale=scale)
-    elif model_name in ("global", "local", "global-with-features", "local-with-features", "encoder"):
+    elif model_name == "global":
+        generator = GlobalGenerator(input_nc, output_nc, ngf, n_downsampling, opt["gen_blocks"], norm_layer)
+    elif model_name in ("local", "global-with-features", "local-with-features", "encoder"):
         raise NotImplementedError(f"generator '{model_name}' is outside the IR->RGB hot path (SURVEY section 2, row 1)")
     else:
         raise NotImplementedError(f"Generator model named {model_name} is not implemented")

@@ -89,11 +89,28 @@ def gen_case(name, model_name, ngf, H, W, seed, scale=0):
     print(name, "params", sum(p.numel() for p in g_ref.parameters()))
 
 
-def dis_case(name, input_nc, H, W, seed):
+def global_case(name, ngf, H, W, seed):
+    """BASELINE config 1: the pix2pixHD global generator (networks.py:320-352) on a single 3-channel frame."""
     torch.manual_seed(seed)
-    d_ref = ref.build_discriminator_module(input_nc, 64, 3, "batch", 2, True)
+    g_ref = ref.build_generator_module(3, 3, 0, ngf, "global", 3, "batch", 0, **OPT)
     torch.manual_seed(seed)
-    d_mine = mine.build_discriminator_module(input_nc, 64, 3, "batch", 2, True)
+    g_mine = mine.build_generator_module(3, 3, 0, ngf, "global", 3, "batch", 0, **OPT)
+    assert_same_init(g_ref, g_mine)
+    x = smooth((1, 3, H, W), seed + 1)
+    g_ref.train()
+    with torch.no_grad():
+        out = g_ref(x)
+    ck = checks(g_mine.state_dict())
+    np.savez_compressed(os.path.join(OUT, f"net_{name}.npz"), seed=seed, ngf=ngf, x=x.numpy(), out=out.numpy(),
+                        check_keys=np.array(list(ck.keys())), check_vals=np.stack(list(ck.values())))
+    print(name, "params", sum(p.numel() for p in g_ref.parameters()))
+
+
+def dis_case(name, input_nc, H, W, seed, ndf=64, num_D=2):
+    torch.manual_seed(seed)
+    d_ref = ref.build_discriminator_module(input_nc, ndf, 3, "batch", num_D, True)
+    torch.manual_seed(seed)
+    d_mine = mine.build_discriminator_module(input_nc, ndf, 3, "batch", num_D, True)
     assert_same_init(d_ref, d_mine)
     x = smooth((2, input_nc, H, W), seed + 1)
     d_ref.train()
@@ -102,14 +119,22 @@ def dis_case(name, input_nc, H, W, seed):
     ck = checks(d_mine.state_dict())
     arrs = {f"out{i}_{j}": (o.numpy().astype(np.float16) if o.shape[1] > 1 else o.numpy())
             for i, sc in enumerate(out) for j, o in enumerate(sc)}
-    np.savez_compressed(os.path.join(OUT, f"net_{name}.npz"), seed=seed, input_nc=input_nc, x=x.numpy(),
+    np.savez_compressed(os.path.join(OUT, f"net_{name}.npz"), seed=seed, input_nc=input_nc, ndf=ndf, num_D=num_D, x=x.numpy(),
                         check_keys=np.array(list(ck.keys())), check_vals=np.stack(list(ck.values())), **arrs)
     print(name, "params", sum(p.numel() for p in d_ref.parameters()))
 
 
 if __name__ == "__main__":
-    gen_case("G0_ngf64_32x64", "composite", 64, 32, 64, seed=11)
-    gen_case("G1_ngf64_32x64", "composite-local", 64, 32, 64, seed=12, scale=1)
-    dis_case("D_nc6_64x96", 6, 64, 96, seed=13)
-    dis_case("DT_nc13_48x80", 13, 48, 80, seed=14)
+    import sys
+    new_only = "new" in sys.argv[1:]          # round-2 additions only (the round-1 files stay byte-identical)
+    if not new_only:
+        gen_case("G0_ngf64_32x64", "composite", 64, 32, 64, seed=11)
+        gen_case("G1_ngf64_32x64", "composite-local", 64, 32, 64, seed=12, scale=1)
+        dis_case("D_nc6_64x96", 6, 64, 96, seed=13)
+        dis_case("DT_nc13_48x80", 13, 48, 80, seed=14)
+    # widths that are not multiples of 64 (generator.py:36 halves ngf per spatial scale: n_scales_spatial=3 gives 32, 16)
+    gen_case("G0_ngf32_32x64", "composite", 32, 32, 64, seed=15)
+    gen_case("G2_ngf16_32x64", "composite-local", 16, 32, 64, seed=16, scale=2)
+    dis_case("D_ndf32_nc6_64x96", 6, 64, 96, seed=17, ndf=16, num_D=3)
+    global_case("GG_ngf128_256x256", 128, 256, 256, seed=18)      # BASELINE.json configs[0]
     print("ok")
