@@ -26,15 +26,19 @@ def test_generator_init_matches_reference(golden_dir):
     for f in sorted(glob.glob(os.path.join(golden_dir, "net_G*.npz"))):
         g = np.load(f)
         torch.manual_seed(int(g["seed"]))
-        m = N.build_generator_module(9, 3, 6, int(g["ngf"]), str(g["model_name"]), 3, "batch", int(g["scale"]), **OPT)
+        if "model_name" in g:
+            m = N.build_generator_module(9, 3, 6, int(g["ngf"]), str(g["model_name"]), 3, "batch", int(g["scale"]), **OPT)
+        else:       # the 'global' generator of BASELINE config 1
+            m = N.build_generator_module(3, 3, 0, int(g["ngf"]), "global", 3, "batch", 0, **OPT)
         _check_init(m, g)
 
 
 def test_discriminator_init_matches_reference(golden_dir):
     for f in sorted(glob.glob(os.path.join(golden_dir, "net_D*.npz"))):
         g = np.load(f)
+        ndf, num_D = (int(g["ndf"]), int(g["num_D"])) if "ndf" in g else (64, 2)
         torch.manual_seed(int(g["seed"]))
-        _check_init(N.build_discriminator_module(int(g["input_nc"]), 64, 3, "batch", 2, True), g)
+        _check_init(N.build_discriminator_module(int(g["input_nc"]), ndf, 3, "batch", num_D, True), g)
 
 
 def test_generator_state_dict_keys():
@@ -80,7 +84,18 @@ def test_unsupported_configurations_raise():
     with pytest.raises(NotImplementedError):
         N.build_generator_module(9, 3, 6, 64, "nonsense", 3, "batch", 0, **OPT)
     with pytest.raises(NotImplementedError):
-        N.build_generator_module(9, 3, 6, 48, "composite", 3, "batch", 0, **OPT)
+        N.build_generator_module(9, 3, 6, 64, "local", 3, "batch", 0, **OPT)      # pix2pixHD LocalEnhancer: not on the path
+
+
+def test_any_width_builds_with_reference_shapes():
+    """generator.py:36 halves ngf per spatial scale, networks.py:634-637 scales ndf per discriminator: no 64-multiple rule."""
+    g = N.build_generator_module(9, 3, 6, 48, "composite", 3, "batch", 0, **OPT)
+    assert g.model_down_seg[1].weight.shape == (48, 9, 7, 7) and g.model_res_img[0].conv_block[1].weight.shape == (384, 384, 3, 3)
+    gl = N.build_generator_module(3, 3, 0, 128, "global", 3, "batch", 0, **OPT)
+    assert list(gl.state_dict())[0] == "model.1.weight" and gl.model[-2].weight.shape == (3, 128, 7, 7)
+    assert sum(p.numel() for p in gl.parameters()) == 182356995
+    d = N.build_discriminator_module(6, 16, 3, "batch", 3, True)
+    assert [getattr(d, f"scale{i}_layer0")[0].out_channels for i in range(3)] == [16, 32, 64]
 
 
 def test_cpu_forward_is_refused():
