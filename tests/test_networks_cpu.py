@@ -95,7 +95,7 @@ def test_any_width_builds_with_reference_shapes():
     assert list(gl.state_dict())[0] == "model.1.weight" and gl.model[-2].weight.shape == (3, 128, 7, 7)
     assert sum(p.numel() for p in gl.parameters()) == 182356995
     d = N.build_discriminator_module(6, 16, 3, "batch", 3, True)
-    assert [getattr(d, f"scale{i}_layer0")[0].out_channels for i in range(3)] == [16, 32, 64]
+    assert [getattr(d, f"scale{i}_layer0")[0].out_channels for i in range(3)] == [64, 32, 16]
 
 
 def test_cpu_forward_is_refused():
