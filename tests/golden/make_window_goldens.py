@@ -53,6 +53,7 @@ from window_stub import smooth, stub_flow_and_conf, stub_flownetc          # noq
 from ir2rgb_amd import networks as mine                                    # noqa: E402
 from ir2rgb_amd.flownet2_pytorch import models as mine_fn                  # noqa: E402
 from oracle import closed_form                                             # noqa: E402
+from oracle import emulated                                                # noqa: E402
 
 G_OPT = dict(gen_blocks=9, n_blocks_local=3, fg=False, no_flow=False, n_local_enhancers=1, feat_num=3)
 
@@ -192,6 +193,14 @@ class RefModelD:
     loss_names = ["G_VGG", "G_GAN", "G_GAN_Feat", "D_real", "D_fake", "G_Warp", "F_Flow", "F_Warp", "W"]
     loss_names_T = ["G_T_GAN", "G_T_GAN_Feat", "D_T_real", "D_T_fake", "G_T_Warp"]
 
+    emulate = None      # a torch half dtype: evaluate the SAME statements with oracle/emulated.py (rounding floor)
+
+    def _D(self, net, x):
+        return net.forward(x) if self.emulate is None else emulated.discriminator_forward(net, x, self.emulate)
+
+    def _feat(self, a, b):
+        return self.criterionFeat(a, b) if self.emulate is None else emulated.l1_half(a, b, 1.0, self.emulate)
+
     def __init__(self, opt, seeds):
         self.opt = opt
         self.tD, self.output_nc = opt["n_frames_D"], opt["output_nc"]
@@ -255,11 +264,11 @@ class RefModelD:
     def compute_loss_D(self, netD, real_A, real_B, fake_B):                 # discriminator.py:154-166
         real_AB = torch.cat((real_A, real_B), dim=1)
         fake_AB = torch.cat((real_A, fake_B), dim=1)
-        pred_real = netD.forward(real_AB)
-        pred_fake = netD.forward(fake_AB.detach())
+        pred_real = self._D(netD, real_AB)
+        pred_fake = self._D(netD, fake_AB.detach())
         loss_D_real = self.criterionGAN(pred_real, True)
         loss_D_fake = self.criterionGAN(pred_fake, False)
-        pred_fake = netD.forward(fake_AB)
+        pred_fake = self._D(netD, fake_AB)
         loss_G_GAN, loss_G_GAN_Feat = self.GAN_and_FM_loss(pred_real, pred_fake)
         return loss_D_real, loss_D_fake, loss_G_GAN, loss_G_GAN_Feat
 
@@ -271,11 +280,11 @@ class RefModelD:
             flow_ref = flow_ref.view(-1, 2 * (self.tD - 1), self.height, self.width)
             real_B = torch.cat([real_B, flow_ref], dim=1)
             fake_B = torch.cat([fake_B, flow_ref], dim=1)
-        pred_real = netD_T.forward(real_B)
-        pred_fake = netD_T.forward(fake_B.detach())
+        pred_real = self._D(netD_T, real_B)
+        pred_fake = self._D(netD_T, fake_B.detach())
         loss_D_T_real = self.criterionGAN(pred_real, True)
         loss_D_T_fake = self.criterionGAN(pred_fake, False)
-        pred_fake = netD_T.forward(fake_B)
+        pred_fake = self._D(netD_T, fake_B)
         loss_G_T_GAN, loss_G_T_GAN_Feat = self.GAN_and_FM_loss(pred_real, pred_fake)
         return loss_D_T_real, loss_D_T_fake, loss_G_T_GAN, loss_G_T_GAN_Feat
 
@@ -288,7 +297,7 @@ class RefModelD:
             for i in range(min(len(pred_fake), self.opt["num_D"])):
                 for j in range(len(pred_fake[i]) - 1):
                     loss_G_GAN_Feat += D_weights * feat_weights * \
-                        self.criterionFeat(pred_fake[i][j], pred_real[i][j].detach()) * self.opt["lambda_feat"]
+                        self._feat(pred_fake[i][j], pred_real[i][j].detach()) * self.opt["lambda_feat"]
         return loss_G_GAN, loss_G_GAN_Feat
 
     def get_all_skipped_frames(self, frames_all, real_B, fake_B, flow_ref, conf_ref, t_scales, tD, flowNet):   # :219-234
@@ -459,10 +468,16 @@ class RefModelG:
             params += list(self.netG[s].parameters())
         self.optimizer_G = torch.optim.Adam(params, lr=opt["lr"], betas=(opt["beta1"], 0.999))
 
+    emulate = None      # as RefModelD.emulate
+
     def _net(self, s, A, prev, feat, flow_feat, use_raw_only):
         """netG.forward (networks.py:191-220 / :288-317); the warp + blend of :207-209 / :305-307 applied outside
         because BaseCompositeGeneratorModule.resample calls .cuda() (networks.py:93-100)."""
-        _, flow, weight, raw, feat, flow_feat, _ = self.netG[s](A, prev, None, feat, flow_feat, None, True)
+        if self.emulate is None:
+            _, flow, weight, raw, feat, flow_feat, _ = self.netG[s](A, prev, None, feat, flow_feat, None, True)
+        else:
+            _, flow, weight, raw, feat, flow_feat, _ = emulated.generator_forward(self.netG[s], A, prev, feat, flow_feat, True,
+                                                                                  dtype=self.emulate)
         if use_raw_only:
             return raw, flow, weight, raw, feat, flow_feat
         b, _, h, w = raw.shape
@@ -532,6 +547,63 @@ G_KEEP = ("model_down_seg.1.weight", "model_down_seg.2.weight", "model_down_img.
           "model_up_flow.1.weight", "model_down_seg.11.bias")
 
 
+def _first_window(model_g, model_d, input_A, input_B, t_scales, tD):
+    """Window 0 (no temporal scale is active yet), gradients left in .grad, nothing stepped, running statistics
+    restored: -> (loss dict, outputs)."""
+    nets = list(model_g.netG) + [model_d.netD]
+    saved = [{k: v.clone() for k, v in n.state_dict().items()} for n in nets]
+    fake_B, fake_B_raw, flow, weight, real_A, real_Bp, _ = model_g.forward(input_A, input_B, None)
+    real_B_prev, real_B = real_Bp[:, :-1], real_Bp[:, 1:]
+    flow_ref, conf_ref = stub_flow_and_conf(real_B, real_B_prev)
+    fake_B_prev = model_g.compute_fake_B_prev(real_B_prev, None, fake_B)
+    losses = model_d.forward(0, reshape([real_B, fake_B, fake_B_raw, real_A, real_B_prev, fake_B_prev, flow, weight, flow_ref, conf_ref]))
+    loss_dict = dict(zip(model_d.loss_names, [torch.mean(x) for x in losses]))
+    loss_G, loss_D, _, _ = model_d.get_losses(loss_dict, [], t_scales)
+    model_g.optimizer_G.zero_grad()
+    loss_G.backward()
+    gG = [{k: p.grad.clone() for k, p in g.named_parameters() if p.grad is not None} for g in model_g.netG]
+    model_d.optimizer_D.zero_grad()
+    loss_D.backward()
+    gD = {k: p.grad.clone() for k, p in model_d.netD.named_parameters() if p.grad is not None}
+    model_g.optimizer_G.zero_grad()
+    model_d.optimizer_D.zero_grad()
+    for n, sd in zip(nets, saved):
+        n.load_state_dict(sd)
+    rec = {k: v.item() for k, v in loss_dict.items()}
+    rec.update(G=loss_G.item(), D=loss_D.item())
+    outs = dict(fake_B=fake_B.detach(), fake_B_raw=fake_B_raw.detach(), flow=flow.detach(), weight=weight.detach())
+    return rec, outs, gG, gD
+
+
+def rounding_floor(model_g, model_d, input_A, input_B, t_scales, tD):
+    """What half-precision storage alone costs on window 0: the same statements evaluated with oracle/emulated.py
+    (fp32 torch operators, values rounded where the HIP path stores a half tensor) against the fp32 run, per loss term,
+    output and stored gradient tensor: relative error / relative L2 / |projection - 1|.  The GPU test holds the HIP
+    path to a multiple of this independently measured floor instead of to a guessed tolerance."""
+    ref_rec, ref_out, ref_gG, ref_gD = _first_window(model_g, model_d, input_A, input_B, t_scales, tD)
+    floors = {}
+    for name, dt in (("f16", torch.float16), ("bf16", torch.bfloat16)):
+        model_g.emulate = model_d.emulate = dt
+        rec, outs, gG, gD = _first_window(model_g, model_d, input_A, input_B, t_scales, tD)
+        model_g.emulate = model_d.emulate = None
+        for k, v in rec.items():
+            floors[f"floor/{name}/loss/{k}"] = abs(v - ref_rec[k]) / max(abs(ref_rec[k]), 0.05)
+        for k, v in outs.items():
+            floors[f"floor/{name}/out/{k}"] = ((v - ref_out[k]).norm() / ref_out[k].norm()).item()
+        for prefix, got, want, keep in [(f"G{s}", gG[s], ref_gG[s], G_KEEP) for s in range(len(gG))] + [("D", gD, ref_gD, D_KEEP)]:
+            for k in keep:
+                if k in want and k in got and want[k].norm() > 0:
+                    a, b = got[k].double().flatten(), want[k].double().flatten()
+                    floors[f"floor/{name}/{prefix}/l2/{k}"] = ((a - b).norm() / b.norm()).item()
+                    floors[f"floor/{name}/{prefix}/proj/{k}"] = abs((a @ b / (b @ b)).item() - 1.0)
+            tot_a = torch.sqrt(sum(v.double().pow(2).sum() for v in got.values()))
+            tot_b = torch.sqrt(sum(v.double().pow(2).sum() for v in want.values()))
+            floors[f"floor/{name}/{prefix}/total_norm"] = abs(tot_a / tot_b - 1).item()
+        print("rounding floor", name, {k.split("/", 2)[2]: round(v, 4) for k, v in floors.items() if k.startswith(f"floor/{name}/")
+                                       and ("out/" in k or "proj" in k or "l2" in k)}, flush=True)
+    return {k: np.float64(v) for k, v in floors.items()}
+
+
 def window_case(tag, n_windows, H, W, no_first_img=False, n_scales_spatial=1, ngf=64, seed=90):
     opt = dict(BASE_OPT, no_first_img=no_first_img, n_scales_spatial=n_scales_spatial, first_layer_gen_filters=ngf)
     model_g = RefModelG(opt, seed)
@@ -542,6 +614,7 @@ def window_case(tag, n_windows, H, W, no_first_img=False, n_scales_spatial=1, ng
     out = {"seq_A": seq_A.numpy(), "seq_B": seq_B.numpy()}
     fake_B_prev_last = None
     frames_all = (None, None, None, None)
+    out.update(rounding_floor(model_g, model_d, seq_A[:, 0:tG], seq_B[:, 0:tG], t_scales, tD))
     for i in range(n_windows):                                              # train_vid2vid.py:54-111, 3-frame windows
         input_A, input_B = seq_A[:, i:i + tG], seq_B[:, i:i + tG]
         fake_B, fake_B_raw, flow, weight, real_A, real_Bp, fake_B_last = model_g.forward(input_A, input_B, fake_B_prev_last)

@@ -12,12 +12,11 @@ Tolerances (half-precision MFMA path against the reference's fp32 CPU run; measu
                         sign(a-b): every sign that flips under rounding is a full-size error.  That this is rounding and
                         not structure is shown by tests/test_backward_gpu.py: against an evaluation that rounds where the
                         HIP path rounds, the same discriminators' gradients agree to 1.5e-2 in both dtypes.
-  multi-window runs     loss scalars 3e-2 (f16) / 6e-2 (bf16): eight Adam steps (|dw| = lr per step whatever the
-                        gradient's size) feed rounding differences back into the weights.  img_raw / flow / weight:
-                        3e-2 / 6e-2.  fake_B (the blend through the warp) 8e-2 / 3e-1: random-init flow heads emit
-                        +-40 px flows, a 0.3 % flow difference moves the sampling point by 0.1 px of a textured image.
-                        Generator gradients of window 0: per-parameter NORMS within 15 % / 35 %, head tensors 8e-2 / 2e-1,
-                        deep tensors at the chaos bound of tests/test_backward_gpu.py (a sanity check only).
+  whole windows         window 0: every output and gradient tensor within max(1.5 x floor, floor + 0.02) of the fp32
+                        reference, where ``floor`` is the distance the golden script measured between the fp32 run and an
+                        independent rounding-emulating evaluation of the same statements (so the bound is what half
+                        storage costs, no more); later windows: loss scalars 3e-2 (f16) / 6e-2 (bf16) -- Adam steps
+                        (|dw| = lr whatever the gradient's size) feed rounding differences back into the weights.
   FlowNet sub-networks  relative L2 <= 1e-2 (bf16 operands, ~20 layers), composition <= 2e-2, confidence mask: at most
                         2 % of the pixels on the other side of the 0.02 threshold
 """
@@ -36,10 +35,6 @@ from window_stub import stub_flow_and_conf, stub_flownetc  # noqa: E402
 LOSS_TOL = {torch.float16: 5e-3, torch.bfloat16: 2e-2}
 GRAD_TOL = {torch.float16: 5e-2, torch.bfloat16: 1.2e-1}
 SEQ_TOL = {torch.float16: 3e-2, torch.bfloat16: 6e-2}
-WARPED_TOL = {torch.float16: 8e-2, torch.bfloat16: 3e-1}
-G_NORM_TOL = {torch.float16: 0.15, torch.bfloat16: 0.35}
-G_HEAD_TOL = {torch.float16: 8e-2, torch.bfloat16: 2e-1}
-G_DEEP_TOL = {torch.float16: 0.45, torch.bfloat16: 0.8}
 
 
 def rel_l2(a, ref):
@@ -244,16 +239,28 @@ def _seeded_trainer(g, dev, dtype):
     return tr
 
 
+def _floor_tol(floor, mult=1.5, add=0.02):
+    return max(mult * floor, floor + add)
+
+
 @pytest.mark.parametrize("case,dtype", [("ngf64_64x128", torch.float16), ("ngf64_64x128", torch.bfloat16),
-                                        ("2scale_ngf128_64x128", torch.float16)])
+                                        ("2scale_ngf128_64x128", torch.float16), ("2scale_ngf128_64x128", torch.bfloat16)])
 def test_training_windows_vs_reference_golden(dev, golden_dir, case, dtype):
     """Vid2VidTrainer.train_window, window after window (recurrence over generated frames, temporal bookkeeping over
-    up to 7 frames, three backward passes and three Adam steps per window) against the reference's loop body."""
+    up to 7 frames, three backward passes and three Adam steps per window) against the reference's loop body.
+
+    Tolerances are DERIVED, not guessed: the golden file carries, for window 0, the distance between the reference's fp32
+    run and an independent evaluation of the same statements that rounds where the HIP path stores half tensors
+    (oracle/emulated.py on the CPU; ``floor/...`` entries).  The HIP path must stay within max(1.5 x floor, floor + 0.02)
+    per output / gradient tensor (relative L2 and |projection - 1|) and within max(3 x floor, 2e-3) per loss term.  In
+    the later windows (weights moved by Adam steps whose direction rounding can flip) losses are held to 3e-2 (f16) /
+    6e-2 (bf16) and outputs to 2 x floor + 0.02."""
     g = np.load(os.path.join(golden_dir, f"window_{case}.npz"))
+    fl = "f16" if dtype == torch.float16 else "bf16"
+    floor = {k[len(f"floor/{fl}/"):]: float(g[k]) for k in g.files if k.startswith(f"floor/{fl}/")}
     tr = _seeded_trainer(g, dev, dtype)
     A, B = torch.from_numpy(g["seq_A"]).to(dev), torch.from_numpy(g["seq_B"]).to(dev)
     tG = tr.opt["n_input_gen_frames"]
-    tol, gtol = SEQ_TOL[dtype], GRAD_TOL[dtype]
     worst = {}
     for i in range(int(g["n_windows"])):
         out = tr.train_window(A[:, i:i + tG], B[:, i:i + tG])
@@ -263,23 +270,40 @@ def test_training_windows_vs_reference_golden(dev, golden_dir, case, dtype):
         assert not missing, f"window {i}: terms not produced: {missing}"
         assert {k for k in got if k not in ref} == set(), f"window {i}: unexpected terms {set(got) - set(ref)}"
         errs = {k: abs(got[k] - ref[k]) / max(abs(ref[k]), 0.05) for k in got}
-        fake_B, fake_B_raw, flow, weight = tr.last_outputs
-        errs["fake_B"] = rel_l2(fake_B, g[f"w{i}/fake_B"].astype(np.float32))
-        errs["fake_B_raw"] = rel_l2(fake_B_raw, g[f"w{i}/fake_B_raw"].astype(np.float32))
-        errs["flow"] = rel_l2(flow, g[f"w{i}/flow"].astype(np.float32))
-        errs["weight"] = rel_l2(weight, g[f"w{i}/weight"].astype(np.float32))
+        tols = {k: (max(3 * floor.get(f"loss/{k}", 0.0), 2e-3) if i == 0 else SEQ_TOL[dtype]) for k in got}
+        for name, t in zip(("fake_B", "fake_B_raw", "flow", "weight"), tr.last_outputs):
+            errs[name] = rel_l2(t, g[f"w{i}/{name}"].astype(np.float32))
+            tols[name] = _floor_tol(floor[f"out/{name}"]) if i == 0 else 2 * floor[f"out/{name}"] + 0.02
         print(case, dtype, "window", i, {k: round(v, 4) for k, v in errs.items()})
         for k, v in errs.items():
             worst[k] = max(worst.get(k, 0.0), v)
-        bad = {k: v for k, v in errs.items() if v > (WARPED_TOL[dtype] if k == "fake_B" else tol)}
-        assert not bad, f"window {i}: over tolerance {tol}: {bad}"
+        bad = {k: (v, tols[k]) for k, v in errs.items() if v > tols[k]}
+        assert not bad, f"window {i}: (error, tolerance) {bad}"
         if i == 0:      # gradients as they stood between backward() and step() (Adam does not touch them)
-            head = lambda k: G_HEAD_TOL[dtype] if ("final" in k or k == "model_up_img.7.bias") else G_DEEP_TOL[dtype]  # noqa: E731
-            for s, net in enumerate(tr.netG):
-                _check_param_grads(f"w0/G{s}/", net, g, None, f"{case} {dtype} netG{s}", norm_tol=G_NORM_TOL[dtype], tensor_tol=head)
-            _check_param_grads("w0/D/", tr.netD, g, gtol, f"{case} {dtype} netD")
+            nets = [(f"G{s}", net) for s, net in enumerate(tr.netG)] + [("D", tr.netD)]
+            report = {}
+            for tag, net in nets:
+                params = dict(net.named_parameters())
+                names = [str(k) for k in g[f"w0/{tag}/grad_names"]]
+                assert list(params.keys()) == names
+                tot_h = np.sqrt(sum(float(p.grad.double().pow(2).sum()) for p in params.values() if p.grad is not None))
+                tot_r = float(np.sqrt((g[f"w0/{tag}/grad_norms"] ** 2).sum()))
+                e = abs(tot_h / tot_r - 1)
+                assert e <= _floor_tol(floor[f"{tag}/total_norm"], 2.0, 0.02), (tag, "total gradient norm", e)
+                for key in g.files:
+                    if not key.startswith(f"w0/{tag}/grad/"):
+                        continue
+                    k = key[len(f"w0/{tag}/grad/"):]
+                    if f"{tag}/l2/{k}" not in floor:
+                        continue      # a bias in front of BatchNorm: zero on both sides
+                    a, b = params[k].grad.detach().double().cpu().flatten(), torch.from_numpy(g[key]).double().flatten()
+                    l2, pr = ((a - b).norm() / b.norm()).item(), abs((a @ b / (b @ b)).item() - 1.0)
+                    report[f"{tag}/{k}"] = (round(l2, 4), round(floor[f"{tag}/l2/{k}"], 4), round(pr, 4), round(floor[f"{tag}/proj/{k}"], 4))
+                    assert l2 <= _floor_tol(floor[f"{tag}/l2/{k}"]), (tag, k, "relative L2", l2, floor[f"{tag}/l2/{k}"])
+                    assert pr <= _floor_tol(floor[f"{tag}/proj/{k}"], 1.5, 0.03), (tag, k, "projection", pr, floor[f"{tag}/proj/{k}"])
+            print(case, dtype, "window-0 gradients (l2, floor, |proj-1|, floor):", report)
     print(case, dtype, "worst per term", {k: round(v, 4) for k, v in worst.items()})
-    # what eight Adam steps did to a few tensors: the update direction must agree (each step moves a weight by ~lr)
+    # what the Adam steps did to a few tensors: the update direction must agree (each step moves a weight by ~lr)
     sdG, sdD = tr.netG[-1].state_dict(), tr.netD.state_dict()
     for key in g.files:
         if key.startswith("after/"):
