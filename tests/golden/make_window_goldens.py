@@ -547,75 +547,13 @@ G_KEEP = ("model_down_seg.1.weight", "model_down_seg.2.weight", "model_down_img.
           "model_up_flow.1.weight", "model_down_seg.11.bias")
 
 
-def _first_window(model_g, model_d, input_A, input_B, t_scales, tD):
-    """Window 0 (no temporal scale is active yet), gradients left in .grad, nothing stepped, running statistics
-    restored: -> (loss dict, outputs)."""
-    nets = list(model_g.netG) + [model_d.netD]
-    saved = [{k: v.clone() for k, v in n.state_dict().items()} for n in nets]
-    fake_B, fake_B_raw, flow, weight, real_A, real_Bp, _ = model_g.forward(input_A, input_B, None)
-    real_B_prev, real_B = real_Bp[:, :-1], real_Bp[:, 1:]
-    flow_ref, conf_ref = stub_flow_and_conf(real_B, real_B_prev)
-    fake_B_prev = model_g.compute_fake_B_prev(real_B_prev, None, fake_B)
-    losses = model_d.forward(0, reshape([real_B, fake_B, fake_B_raw, real_A, real_B_prev, fake_B_prev, flow, weight, flow_ref, conf_ref]))
-    loss_dict = dict(zip(model_d.loss_names, [torch.mean(x) for x in losses]))
-    loss_G, loss_D, _, _ = model_d.get_losses(loss_dict, [], t_scales)
-    model_g.optimizer_G.zero_grad()
-    loss_G.backward()
-    gG = [{k: p.grad.clone() for k, p in g.named_parameters() if p.grad is not None} for g in model_g.netG]
-    model_d.optimizer_D.zero_grad()
-    loss_D.backward()
-    gD = {k: p.grad.clone() for k, p in model_d.netD.named_parameters() if p.grad is not None}
-    model_g.optimizer_G.zero_grad()
-    model_d.optimizer_D.zero_grad()
-    for n, sd in zip(nets, saved):
-        n.load_state_dict(sd)
-    rec = {k: v.item() for k, v in loss_dict.items()}
-    rec.update(G=loss_G.item(), D=loss_D.item())
-    outs = dict(fake_B=fake_B.detach(), fake_B_raw=fake_B_raw.detach(), flow=flow.detach(), weight=weight.detach())
-    return rec, outs, gG, gD
-
-
-def rounding_floor(model_g, model_d, input_A, input_B, t_scales, tD):
-    """What half-precision storage alone costs on window 0: the same statements evaluated with oracle/emulated.py
-    (fp32 torch operators, values rounded where the HIP path stores a half tensor) against the fp32 run, per loss term,
-    output and stored gradient tensor: relative error / relative L2 / |projection - 1|.  The GPU test holds the HIP
-    path to a multiple of this independently measured floor instead of to a guessed tolerance."""
-    ref_rec, ref_out, ref_gG, ref_gD = _first_window(model_g, model_d, input_A, input_B, t_scales, tD)
-    floors = {}
-    for name, dt in (("f16", torch.float16), ("bf16", torch.bfloat16)):
-        model_g.emulate = model_d.emulate = dt
-        rec, outs, gG, gD = _first_window(model_g, model_d, input_A, input_B, t_scales, tD)
-        model_g.emulate = model_d.emulate = None
-        for k, v in rec.items():
-            floors[f"floor/{name}/loss/{k}"] = abs(v - ref_rec[k]) / max(abs(ref_rec[k]), 0.05)
-        for k, v in outs.items():
-            floors[f"floor/{name}/out/{k}"] = ((v - ref_out[k]).norm() / ref_out[k].norm()).item()
-        for prefix, got, want, keep in [(f"G{s}", gG[s], ref_gG[s], G_KEEP) for s in range(len(gG))] + [("D", gD, ref_gD, D_KEEP)]:
-            for k in keep:
-                if k in want and k in got and want[k].norm() > 0:
-                    a, b = got[k].double().flatten(), want[k].double().flatten()
-                    floors[f"floor/{name}/{prefix}/l2/{k}"] = ((a - b).norm() / b.norm()).item()
-                    floors[f"floor/{name}/{prefix}/proj/{k}"] = abs((a @ b / (b @ b)).item() - 1.0)
-            tot_a = torch.sqrt(sum(v.double().pow(2).sum() for v in got.values()))
-            tot_b = torch.sqrt(sum(v.double().pow(2).sum() for v in want.values()))
-            floors[f"floor/{name}/{prefix}/total_norm"] = abs(tot_a / tot_b - 1).item()
-        print("rounding floor", name, {k.split("/", 2)[2]: round(v, 4) for k, v in floors.items() if k.startswith(f"floor/{name}/")
-                                       and ("out/" in k or "proj" in k or "l2" in k)}, flush=True)
-    return {k: np.float64(v) for k, v in floors.items()}
-
-
-def window_case(tag, n_windows, H, W, no_first_img=False, n_scales_spatial=1, ngf=64, seed=90):
-    opt = dict(BASE_OPT, no_first_img=no_first_img, n_scales_spatial=n_scales_spatial, first_layer_gen_filters=ngf)
-    model_g = RefModelG(opt, seed)
-    model_d = RefModelD(opt, seeds=(seed + 1, seed + 2))
+def run_windows(model_g, model_d, seq_A, seq_B, n_windows, opt, record_grads=True, tag=""):
+    """train_vid2vid.py:54-111 over 3-frame windows.  -> per-window records {loss terms, outputs}, window-0 gradients."""
     tG, tD, t_scales = opt["n_input_gen_frames"], opt["n_frames_D"], opt["n_scales_temporal"]
-    n_frames = n_windows + tG - 1
-    seq_A, seq_B = smooth((1, n_frames, 3, H, W), seed + 5), smooth((1, n_frames, 3, H, W), seed + 6)
-    out = {"seq_A": seq_A.numpy(), "seq_B": seq_B.numpy()}
     fake_B_prev_last = None
     frames_all = (None, None, None, None)
-    out.update(rounding_floor(model_g, model_d, seq_A[:, 0:tG], seq_B[:, 0:tG], t_scales, tD))
-    for i in range(n_windows):                                              # train_vid2vid.py:54-111, 3-frame windows
+    recs, grads = [], {}
+    for i in range(n_windows):
         input_A, input_B = seq_A[:, i:i + tG], seq_B[:, i:i + tG]
         fake_B, fake_B_raw, flow, weight, real_A, real_Bp, fake_B_last = model_g.forward(input_A, input_B, fake_B_prev_last)
         real_B_prev, real_B = real_Bp[:, :-1], real_Bp[:, 1:]
@@ -640,35 +578,100 @@ def window_case(tag, n_windows, H, W, no_first_img=False, n_scales_spatial=1, ng
             rec.update({f"{k}{s}": v.item() for k, v in d.items()})
         rec.update({"G": loss_G.item(), "D": loss_D.item()})
         rec.update({f"D_T{s}": v.item() for s, v in enumerate(loss_D_T)})
-        out.update({f"w{i}/loss/{k}": np.float64(v) for k, v in rec.items()})
-        out[f"w{i}/fake_B"] = fake_B.detach().numpy().astype(np.float16)
-        out[f"w{i}/fake_B_raw"] = fake_B_raw.detach().numpy().astype(np.float16)
-        out[f"w{i}/flow"] = flow.detach().numpy().astype(np.float16)
-        out[f"w{i}/weight"] = weight.detach().numpy().astype(np.float16)
+        outs = dict(fake_B=fake_B.detach().clone(), fake_B_raw=fake_B_raw.detach().clone(), flow=flow.detach().clone(),
+                    weight=weight.detach().clone())
+        recs.append((rec, outs))
         # the three loss_backward calls, with the gradients recorded between backward() and step() for window 0
         model_g.optimizer_G.zero_grad()
         loss_G.backward()
-        if i == 0:
+        if i == 0 and record_grads:
             for s, g in enumerate(model_g.netG):
-                out.update(_grad_record(f"w0/G{s}/", g.named_parameters(), G_KEEP))
+                grads[f"G{s}"] = {k: p.grad.clone() for k, p in g.named_parameters() if p.grad is not None}
         model_g.optimizer_G.step()
         model_d.optimizer_D.zero_grad()
         loss_D.backward()
-        if i == 0:
-            out.update(_grad_record("w0/D/", model_d.netD.named_parameters(), D_KEEP))
+        if i == 0 and record_grads:
+            grads["D"] = {k: p.grad.clone() for k, p in model_d.netD.named_parameters() if p.grad is not None}
         model_d.optimizer_D.step()
         for s in range(t_scales_act):
             loss_backward(loss_D_T[s], model_d.optimizer_D_T[s])
         print(f"window {tag} {i}:", {k: round(v, 5) for k, v in rec.items()}, flush=True)
-    # what the optimizers did to a few tensors (Adam, lr 2e-4, beta1 0.5)
+    return recs, grads
+
+
+def window_case(tag, n_windows, H, W, no_first_img=False, n_scales_spatial=1, ngf=64, seed=90, lr=2e-4, floor_windows=1):
+    """One sequence of training windows by the reference's statements, plus -- for the first ``floor_windows`` windows --
+    the ROUNDING FLOOR: the same statements evaluated by oracle/emulated.py (fp32 torch operators, values rounded where
+    the HIP path stores a half tensor; same seeds, its own optimizers) and compared with the fp32 run, per loss term,
+    output and stored gradient tensor (relative error / relative L2 / |projection - 1|).  The GPU test holds the HIP path
+    to a multiple of this independently measured floor instead of to a guessed tolerance.  ``lr=0``: the weights stay
+    put, so every later window checks the recurrence and the temporal bookkeeping without the feedback of Adam steps
+    (whose first step is lr * sign(gradient): one flipped sign moves a weight by 2 lr whatever the gradient's size)."""
+    import copy
+    opt = dict(BASE_OPT, no_first_img=no_first_img, n_scales_spatial=n_scales_spatial, first_layer_gen_filters=ngf, lr=lr)
+    model_g = RefModelG(opt, seed)
+    model_d = RefModelD(opt, seeds=(seed + 1, seed + 2))
+    tG = opt["n_input_gen_frames"]
+    n_frames = n_windows + tG - 1
+    seq_A, seq_B = smooth((1, n_frames, 3, H, W), seed + 5), smooth((1, n_frames, 3, H, W), seed + 6)
+    out = {"seq_A": seq_A.numpy(), "seq_B": seq_B.numpy()}
+    twins = {}
+    for name, dt in (("f16", torch.float16), ("bf16", torch.bfloat16)):     # copies made before anything is stepped
+        tg, td = RefModelG.__new__(RefModelG), RefModelD.__new__(RefModelD)
+        tg.__dict__.update({k: v for k, v in model_g.__dict__.items() if k not in ("netG", "optimizer_G")})
+        td.__dict__.update({k: v for k, v in model_d.__dict__.items() if k not in ("netD", "netD_T", "optimizer_D", "optimizer_D_T")})
+        tg.netG = copy.deepcopy(model_g.netG)
+        td.netD, td.netD_T = copy.deepcopy(model_d.netD), copy.deepcopy(model_d.netD_T)
+        adam = dict(lr=opt["lr"], betas=(opt["beta1"], 0.999))
+        params = list(tg.netG[tg.n_scales - 1].parameters())
+        for s in range(tg.n_scales - 1):
+            params += list(tg.netG[s].parameters())
+        tg.optimizer_G = torch.optim.Adam(params, **adam)
+        td.optimizer_D = torch.optim.Adam(list(td.netD.parameters()), **adam)
+        td.optimizer_D_T = [torch.optim.Adam(list(d.parameters()), **adam) for d in td.netD_T]
+        tg.emulate = td.emulate = dt
+        twins[name] = (tg, td)
+    recs, grads = run_windows(model_g, model_d, seq_A, seq_B, n_windows, opt, tag=tag)
+    for i, (rec, outs) in enumerate(recs):
+        out.update({f"w{i}/loss/{k}": np.float64(v) for k, v in rec.items()})
+        out.update({f"w{i}/{k}": v.numpy().astype(np.float16) for k, v in outs.items()})
+    for s, g in enumerate(model_g.netG):
+        norms = {k: grads[f"G{s}"][k].double().norm().item() if k in grads[f"G{s}"] else 0.0 for k, _ in g.named_parameters()}
+        out[f"w0/G{s}/grad_names"], out[f"w0/G{s}/grad_norms"] = np.array(list(norms)), np.array(list(norms.values()))
+        out.update({f"w0/G{s}/grad/{k}": grads[f"G{s}"][k].numpy() for k in G_KEEP if k in grads[f"G{s}"]})
+    norms = {k: grads["D"][k].double().norm().item() if k in grads["D"] else 0.0 for k, _ in model_d.netD.named_parameters()}
+    out["w0/D/grad_names"], out["w0/D/grad_norms"] = np.array(list(norms)), np.array(list(norms.values()))
+    out.update({f"w0/D/grad/{k}": grads["D"][k].numpy() for k in D_KEEP if k in grads["D"]})
+    # the rounding floor
+    for name, (tg, td) in twins.items():
+        erecs, egrads = run_windows(tg, td, seq_A, seq_B, floor_windows, opt, tag=f"{tag} emulated {name}")
+        fl = {}
+        for i in range(floor_windows):
+            for k, v in erecs[i][0].items():
+                fl[f"floor/{name}/w{i}/loss/{k}"] = abs(v - recs[i][0][k]) / max(abs(recs[i][0][k]), 0.05)
+            for k, v in erecs[i][1].items():
+                fl[f"floor/{name}/w{i}/out/{k}"] = ((v - recs[i][1][k]).norm() / recs[i][1][k].norm()).item()
+        for prefix, keep in [(f"G{s}", G_KEEP) for s in range(len(model_g.netG))] + [("D", D_KEEP)]:
+            got, want = egrads[prefix], grads[prefix]
+            for k in keep:
+                if k in want and k in got and want[k].norm() > 0:
+                    a, b = got[k].double().flatten(), want[k].double().flatten()
+                    fl[f"floor/{name}/{prefix}/l2/{k}"] = ((a - b).norm() / b.norm()).item()
+                    fl[f"floor/{name}/{prefix}/proj/{k}"] = abs((a @ b / (b @ b)).item() - 1.0)
+            tot_a = torch.sqrt(sum(v.double().pow(2).sum() for v in got.values()))
+            tot_b = torch.sqrt(sum(v.double().pow(2).sum() for v in want.values()))
+            fl[f"floor/{name}/{prefix}/total_norm"] = abs(tot_a / tot_b - 1).item()
+        print("rounding floor", tag, name, {k.split("/", 2)[2]: round(v, 4) for k, v in fl.items() if "/out/" in k or "/loss/G" in k}, flush=True)
+        out.update({k: np.float64(v) for k, v in fl.items()})
+    # what the optimizers did to a few tensors (Adam, beta1 0.5)
     sd = model_g.netG[-1].state_dict()
     for k in ("model_final_img.1.weight", "model_final_img.1.bias", "model_down_seg.2.weight"):
         out[f"after/G/{k}"] = sd[k].numpy().copy()
     sd = model_d.netD.state_dict()
     for k in ("scale0_layer0.0.bias", "scale1_layer4.0.weight"):
         out[f"after/D/{k}"] = sd[k].numpy().copy()
-    np.savez_compressed(os.path.join(OUT, f"window_{tag}.npz"), seed=seed, n_windows=n_windows, ngf=ngf,
-                        no_first_img=no_first_img, n_scales_spatial=n_scales_spatial, **out)
+    np.savez_compressed(os.path.join(OUT, f"window_{tag}.npz"), seed=seed, n_windows=n_windows, ngf=ngf, lr=lr,
+                        floor_windows=floor_windows, no_first_img=no_first_img, n_scales_spatial=n_scales_spatial, **out)
 
 
 if __name__ == "__main__":
@@ -680,11 +683,12 @@ if __name__ == "__main__":
         loss_case(False, 1, "s1")
         loss_case(True, 2, "s2_nofirst")
     if "window" in what:
-        window_case("ngf64_64x128", 8, 64, 128)
+        window_case("ngf64_64x128_lr0", 8, 64, 128, lr=0.0)                 # recurrence + temporal bookkeeping, both temporal scales
+        window_case("ngf64_64x128", 3, 64, 128, floor_windows=3)            # with the three Adam steps per window
         # no window golden with no_first_img: its first window feeds all-zero previous frames to model_down_img, whose
         # BatchNorm layers then normalise a constant (variance 0, scale 1/sqrt(eps) = 316): in fp32 the result is the
         # amplified rounding residue of mean(bias) - bias, re-shaped by the zero padding of the next convolution and
         # normalised to O(1) again -- not a function of the weights that another summation order reproduces.  The
         # no_first_img terms of the objective (weight loss, lambda_F / 2^(scales-1)) are pinned by losses_s2_nofirst.
-        window_case("2scale_ngf128_64x128", 2, 64, 128, n_scales_spatial=2, ngf=128, seed=97)
+        window_case("2scale_ngf128_64x128", 2, 64, 128, n_scales_spatial=2, ngf=128, seed=97, floor_windows=2)
     print("ok")

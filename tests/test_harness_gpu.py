@@ -223,7 +223,7 @@ def _seeded_trainer(g, dev, dtype):
     from ir2rgb_amd import vid2vid as V
     seed, ns, ngf = int(g["seed"]), int(g["n_scales_spatial"]), int(g["ngf"])
     tr = V.Vid2VidTrainer(dev, compute_dtype=dtype, first_layer_gen_filters=ngf, n_scales_spatial=ns,
-                          no_first_img=bool(g["no_first_img"]), build_flow_net=False)
+                          no_first_img=bool(g["no_first_img"]), build_flow_net=False, lr=float(g["lr"]))
     o = tr.opt
     kw = {k: o[k] for k in ("gen_blocks", "n_local_enhancers", "feat_num", "n_blocks_local", "fg", "no_flow")}
     tG = o["n_input_gen_frames"]
@@ -243,21 +243,29 @@ def _floor_tol(floor, mult=1.5, add=0.02):
     return max(mult * floor, floor + add)
 
 
-@pytest.mark.parametrize("case,dtype", [("ngf64_64x128", torch.float16), ("ngf64_64x128", torch.bfloat16),
-                                        ("2scale_ngf128_64x128", torch.float16), ("2scale_ngf128_64x128", torch.bfloat16)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("case", ["ngf64_64x128_lr0", "ngf64_64x128", "2scale_ngf128_64x128"])
 def test_training_windows_vs_reference_golden(dev, golden_dir, case, dtype):
     """Vid2VidTrainer.train_window, window after window (recurrence over generated frames, temporal bookkeeping over
     up to 7 frames, three backward passes and three Adam steps per window) against the reference's loop body.
 
-    Tolerances are DERIVED, not guessed: the golden file carries, for window 0, the distance between the reference's fp32
-    run and an independent evaluation of the same statements that rounds where the HIP path stores half tensors
-    (oracle/emulated.py on the CPU; ``floor/...`` entries).  The HIP path must stay within max(1.5 x floor, floor + 0.02)
-    per output / gradient tensor (relative L2 and |projection - 1|) and within max(3 x floor, 2e-3) per loss term.  In
-    the later windows (weights moved by Adam steps whose direction rounding can flip) losses are held to 3e-2 (f16) /
-    6e-2 (bf16) and outputs to 2 x floor + 0.02."""
+    Tolerances are DERIVED, not guessed: the golden file carries, for its first windows, the distance between the
+    reference's fp32 run and an independent run of the same statements that rounds where the HIP path stores half tensors
+    (oracle/emulated.py on the CPU, own optimizers; ``floor/...`` entries).  The HIP path must stay within
+    max(1.5 x floor, floor + 0.02) per output / gradient tensor (relative L2 and |projection - 1|) and within
+    max(3 x floor, 5e-3) per loss term.  Three cases:
+      *_lr0       eight windows with the learning rate at 0: the generated-frame recurrence and the temporal bookkeeping
+                  of both temporal scales, every window at window-0 accuracy (floors of window 0, x2 for the outputs);
+      ngf64       three windows with the three Adam steps each.  Adam's first step is lr * sign(gradient): every sign the
+                  rounding noise flips moves a weight by 2 lr, and the floor shows what that does at this toy size
+                  (64x128, BatchNorm over 128 pixels): outputs of window 1 are 10 % (f16) / 33 % (bf16) from the fp32
+                  run, of window 2 72 % / 82 % -- for the emulated run exactly as for the HIP run.  The loss terms stay
+                  within a few percent and are what these windows check;
+      2scale      two spatial scales (ngf 128 -> 64), two windows."""
     g = np.load(os.path.join(golden_dir, f"window_{case}.npz"))
     fl = "f16" if dtype == torch.float16 else "bf16"
     floor = {k[len(f"floor/{fl}/"):]: float(g[k]) for k in g.files if k.startswith(f"floor/{fl}/")}
+    n_floor = int(g["floor_windows"])
     tr = _seeded_trainer(g, dev, dtype)
     A, B = torch.from_numpy(g["seq_A"]).to(dev), torch.from_numpy(g["seq_B"]).to(dev)
     tG = tr.opt["n_input_gen_frames"]
@@ -270,10 +278,10 @@ def test_training_windows_vs_reference_golden(dev, golden_dir, case, dtype):
         assert not missing, f"window {i}: terms not produced: {missing}"
         assert {k for k in got if k not in ref} == set(), f"window {i}: unexpected terms {set(got) - set(ref)}"
         errs = {k: abs(got[k] - ref[k]) / max(abs(ref[k]), 0.05) for k in got}
-        tols = {k: (max(3 * floor.get(f"loss/{k}", 0.0), 2e-3) if i == 0 else SEQ_TOL[dtype]) for k in got}
+        tols = {k: (max(3 * floor[f"w{i}/loss/{k}"], 5e-3) if i < n_floor else SEQ_TOL[dtype]) for k in got}
         for name, t in zip(("fake_B", "fake_B_raw", "flow", "weight"), tr.last_outputs):
             errs[name] = rel_l2(t, g[f"w{i}/{name}"].astype(np.float32))
-            tols[name] = _floor_tol(floor[f"out/{name}"]) if i == 0 else 2 * floor[f"out/{name}"] + 0.02
+            tols[name] = _floor_tol(floor[f"w{i}/out/{name}"]) if i < n_floor else 2 * floor[f"w0/out/{name}"] + 0.02
         print(case, dtype, "window", i, {k: round(v, 4) for k, v in errs.items()})
         for k, v in errs.items():
             worst[k] = max(worst.get(k, 0.0), v)
