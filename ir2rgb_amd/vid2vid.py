@@ -536,8 +536,15 @@ class Vid2VidTrainer:
         fake_B, fake_B_raw, flow, weight, real_A, real_Bp = self.generate(input_A, input_B)
         real_B_prev, real_B = real_Bp[:, :-1], real_Bp[:, 1:]
         flow_ref, conf_ref, rb_s, extra_flows = self.reference_flows(real_B, real_B_prev)
-        # compute_fake_B_prev (generator.py:283-287)
-        fbp = real_B_prev[:, 0:1] if fake_prev_last is None else fake_prev_last[0][:, -1:]
+        # compute_fake_B_prev (generator.py:283-287) AS THE REFERENCE'S LOOP EVALUATES IT.  train_vid2vid.py:60,:67-68
+        # hands the previous window's pyramid LIST to model_g and afterwards to compute_fake_B_prev; in between,
+        # generate_frame_train appends the new frames to the elements of that very list (generator.py:113, :175:
+        # ``fake_B_pyr[si] = concat([fake_B_pyr[si], fake_B])`` on the caller's object).  So from the second window on
+        # ``fake_B_last[0][:, -1:]`` is the frame generated in THIS window, and G_Warp compares fake_B with its own
+        # flow_ref-warped copy.  Reproduced on purpose (pinned by tests/golden/window_*.npz, whose generating script
+        # executes the reference's statements and therefore has the same aliasing); only the first window of a
+        # sequence uses the given previous frame.
+        fbp = real_B_prev[:, 0:1] if fake_prev_last is None else fake_B[:, -1:].detach()
         if fake_B.size(1) > 1:
             fbp = torch.cat([fbp, fake_B[:, :-1].detach()], 1)
         flat = lambda t: t.reshape((-1,) + tuple(t.shape[2:]))  # noqa: E731
