@@ -252,8 +252,9 @@ def test_training_windows_vs_reference_golden(dev, golden_dir, case, dtype):
     Tolerances are DERIVED, not guessed: the golden file carries, for its first windows, the distance between the
     reference's fp32 run and an independent run of the same statements that rounds where the HIP path stores half tensors
     (oracle/emulated.py on the CPU, own optimizers; ``floor/...`` entries).  The HIP path must stay within
-    max(1.5 x floor, floor + 0.02) per output / gradient tensor (relative L2 and |projection - 1|) and within
-    max(3 x floor, 1e-2) per loss term.  Three cases:
+    max(1.5 x floor, floor + 0.02) per output, max(2 x floor, floor + 0.03) per gradient tensor (relative L2;
+    |projection - 1| likewise, or half the L2 floor) and within max(3 x floor, 1e-2) per loss term of window 0
+    (later windows: max(3 x floor, 3e-2 / 6e-2)).  Three cases:
       *_lr0       eight windows with the learning rate at 0: the generated-frame recurrence and the temporal bookkeeping
                   of both temporal scales, every window at window-0 accuracy (floors of window 0, x2 for the outputs);
       ngf64       three windows with the three Adam steps each.  Adam's first step is lr * sign(gradient): every sign the
@@ -278,10 +279,14 @@ def test_training_windows_vs_reference_golden(dev, golden_dir, case, dtype):
         assert not missing, f"window {i}: terms not produced: {missing}"
         assert {k for k in got if k not in ref} == set(), f"window {i}: unexpected terms {set(got) - set(ref)}"
         errs = {k: abs(got[k] - ref[k]) / max(abs(ref[k]), 0.05) for k in got}
-        tols = {k: (max(3 * floor[f"w{i}/loss/{k}"], 1e-2) if i < n_floor else SEQ_TOL[dtype]) for k in got}
+        tols = {k: (max(3 * floor[f"w{i}/loss/{k}"], 1e-2 if i == 0 else SEQ_TOL[dtype]) if i < n_floor else SEQ_TOL[dtype])
+                for k in got}
         for name, t in zip(("fake_B", "fake_B_raw", "flow", "weight"), tr.last_outputs):
             errs[name] = rel_l2(t, g[f"w{i}/{name}"].astype(np.float32))
-            tols[name] = _floor_tol(floor[f"w{i}/out/{name}"]) if i < n_floor else 2 * floor[f"w0/out/{name}"] + 0.02
+            if i < n_floor:
+                tols[name] = _floor_tol(floor[f"w{i}/out/{name}"])
+            else:       # past the windows with a measured floor: twice the largest floor seen
+                tols[name] = 2 * max(floor[f"w{j}/out/{name}"] for j in range(n_floor)) + 0.02
         print(case, dtype, "window", i, {k: round(v, 4) for k, v in errs.items()})
         for k, v in errs.items():
             worst[k] = max(worst.get(k, 0.0), v)
@@ -307,7 +312,7 @@ def test_training_windows_vs_reference_golden(dev, golden_dir, case, dtype):
                     a, b = params[k].grad.detach().double().cpu().flatten(), torch.from_numpy(g[key]).double().flatten()
                     l2, pr = ((a - b).norm() / b.norm()).item(), abs((a @ b / (b @ b)).item() - 1.0)
                     report[f"{tag}/{k}"] = (round(l2, 4), round(floor[f"{tag}/l2/{k}"], 4), round(pr, 4), round(floor[f"{tag}/proj/{k}"], 4))
-                    assert l2 <= _floor_tol(floor[f"{tag}/l2/{k}"]), (tag, k, "relative L2", l2, floor[f"{tag}/l2/{k}"])
+                    assert l2 <= _floor_tol(floor[f"{tag}/l2/{k}"], 2.0, 0.03), (tag, k, "relative L2", l2, floor[f"{tag}/l2/{k}"])
                     # (zero-mean noise of relative size e moves the projection by at most e: half the L2 floor as a third term)
                     ptol = max(_floor_tol(floor[f"{tag}/proj/{k}"], 1.5, 0.03), 0.5 * floor[f"{tag}/l2/{k}"])
                     assert pr <= ptol, (tag, k, "projection", pr, floor[f"{tag}/proj/{k}"])
