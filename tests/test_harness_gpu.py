@@ -255,8 +255,13 @@ def test_training_windows_vs_reference_golden(dev, golden_dir, case, dtype):
     max(1.5 x floor, floor + 0.02) per output, max(2 x floor, floor + 0.03) per gradient tensor (relative L2;
     |projection - 1| likewise, or half the L2 floor) and within max(3 x floor, 1e-2) per loss term of window 0
     (later windows: max(3 x floor, 3e-2 / 6e-2)).  Three cases:
-      *_lr0       eight windows with the learning rate at 0: the generated-frame recurrence and the temporal bookkeeping
-                  of both temporal scales, every window at window-0 accuracy (floors of window 0, x2 for the outputs);
+      *_lr0       eight windows with the learning rate at 0.  Windows 0-2 run freely against their floors -- which show that
+                  the generated-frame recurrence of a random-init generator is itself chaotic (a 1.7 % difference in the
+                  frame fed back becomes 4 % in the next frame, 48 % in the one after; emulated and HIP run alike).
+                  Windows 3-7 therefore restart from the REFERENCE's generated frames (trainer.fake_B_prev and the
+                  fake-frame history are overwritten from the golden file before each call): every window then checks
+                  the per-window computation and the temporal bookkeeping of both temporal scales (scale 1 needs 7
+                  frames of history) at window-0 accuracy: loss terms 1e-2 / 3e-2, outputs 2 x floor + 0.01;
       ngf64       three windows with the three Adam steps each.  Adam's first step is lr * sign(gradient): every sign the
                   rounding noise flips moves a weight by 2 lr, and the floor shows what that does at this toy size
                   (64x128, BatchNorm over 128 pixels): outputs of window 1 are 10 % (f16) / 33 % (bf16) from the fp32
@@ -271,7 +276,13 @@ def test_training_windows_vs_reference_golden(dev, golden_dir, case, dtype):
     A, B = torch.from_numpy(g["seq_A"]).to(dev), torch.from_numpy(g["seq_B"]).to(dev)
     tG = tr.opt["n_input_gen_frames"]
     worst = {}
+    forced = float(g["lr"]) == 0.0      # see the docstring: windows past the floored ones restart from the reference's frames
     for i in range(int(g["n_windows"])):
+        if forced and i >= n_floor:
+            hist = [B[:, 0], B[:, 1]] + [torch.from_numpy(g[f"w{j}/fake_B"].astype(np.float32)).to(dev)[:, 0] for j in range(i)]
+            tr.fake_B_prev = [torch.stack(hist[-(tG - 1):], 1)]
+            keep = tr.tD ** (tr.t_scales - 1) * (tr.tD - 1)
+            tr.frames_all[1] = torch.stack(hist[2:][-keep:], 1)
         out = tr.train_window(A[:, i:i + tG], B[:, i:i + tG])
         ref = {k.split("/")[-1]: float(g[k]) for k in g.files if k.startswith(f"w{i}/loss/")}
         got = {k: v.item() for k, v in out.items()}
@@ -281,10 +292,14 @@ def test_training_windows_vs_reference_golden(dev, golden_dir, case, dtype):
         errs = {k: abs(got[k] - ref[k]) / max(abs(ref[k]), 0.05) for k in got}
         tols = {k: (max(3 * floor[f"w{i}/loss/{k}"], 1e-2 if i == 0 else SEQ_TOL[dtype]) if i < n_floor else SEQ_TOL[dtype])
                 for k in got}
+        if forced and i >= n_floor:     # every window is a first window again: window-0 accuracy
+            tols = {k: 1e-2 if dtype == torch.float16 else 3e-2 for k in got}
         for name, t in zip(("fake_B", "fake_B_raw", "flow", "weight"), tr.last_outputs):
             errs[name] = rel_l2(t, g[f"w{i}/{name}"].astype(np.float32))
             if i < n_floor:
                 tols[name] = _floor_tol(floor[f"w{i}/out/{name}"])
+            elif forced:
+                tols[name] = 2 * floor[f"w0/out/{name}"] + 0.01
             else:       # past the windows with a measured floor: twice the largest floor seen
                 tols[name] = 2 * max(floor[f"w{j}/out/{name}"] for j in range(n_floor)) + 0.02
         print(case, dtype, "window", i, {k: round(v, 4) for k, v in errs.items()})
