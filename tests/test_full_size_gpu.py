@@ -1,0 +1,76 @@
+"""BASELINE.json's two single-GPU generator configurations AT FULL SIZE against the fp32 oracle (oracle/networks_oracle.py,
+the reference's graph in plain torch, pinned by the reference goldens), evaluated on the host CPU of the GPU box:
+
+  configs[1]  512x1024, bf16: CompositeGenerator(ngf 128) @256x512 -> CompositeLocalGenerator(ngf 64) @512x1024
+  configs[4]  1024x2048, fp16: CompositeGenerator(ngf 128) @512x1024 -> CompositeLocalGenerator(ngf 64) @1024x2048
+
+Same seeded reference init on both sides (bit-identical parameters: tests/test_networks_cpu.py), same smooth synthetic
+frames, train-mode BatchNorm, the coarse scale's features fed to the fine scale exactly as generator.py:139-160 chains
+them.  Bounds: relative L2 per tensor <= 2e-2 for bf16 and <= 5e-3 for f16.  At these sizes BatchNorm
+averages over 2 048 .. 2 M pixels, so the half-precision path sits well inside them (the 32x64 goldens of
+tests/test_networks_gpu.py, BatchNorm over 32 pixels, need 4e-2 for bf16).  img_final is not compared: random-init flow
+heads emit +-40 px flows and the blend amplifies their 1e-3 differences (tests/test_networks_gpu.py checks the blend).
+"""
+import copy
+import time
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+OPT = dict(gen_blocks=9, n_blocks_local=3, fg=False, no_flow=False, n_local_enhancers=1, feat_num=3)
+TOL = {torch.bfloat16: 2e-2, torch.float16: 5e-3}
+
+
+def _smooth(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(shape, generator=g)
+    return torch.tanh(F.avg_pool2d(F.pad(x, (7, 7, 7, 7), mode="reflect"), 15, stride=1) * 6)
+
+
+def _rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
+
+
+def _two_scale(dev, H, W, dtype):
+    from ir2rgb_amd import networks as N
+    from oracle import networks_oracle as NO
+    torch.manual_seed(0)
+    g0 = N.build_generator_module(9, 3, 6, 128, "composite", 3, "batch", 0, **OPT).train()
+    g1 = N.build_generator_module(9, 3, 6, 64, "composite-local", 3, "batch", 1, **OPT).train()
+    r0, r1 = copy.deepcopy(g0), copy.deepcopy(g1)
+    A, P = _smooth((1, 9, H, W), 1), _smooth((1, 6, H, W), 2)
+    pool = lambda t: F.avg_pool2d(t, 3, stride=2, padding=1, count_include_pad=False)   # noqa: E731  base_model.py:64-82
+    A0, P0 = pool(A), pool(P)
+    t0 = time.time()
+    with torch.no_grad():
+        c_ref = NO.generator_forward(r0, A0, P0)
+        f_ref = NO.generator_forward(r1, A, P, c_ref[4], c_ref[5])
+    t_cpu = time.time() - t0
+    g0, g1 = g0.to(dev), g1.to(dev)
+    g0.compute_dtype = g1.compute_dtype = dtype
+    with torch.no_grad():
+        c = g0(A0.to(dev), P0.to(dev), None, None, None, None, False)
+        f = g1(A.to(dev), P.to(dev), None, c[4], c[5], None, False)
+    torch.cuda.synchronize()
+    names = ((1, "flow"), (2, "weight"), (3, "img_raw"), (4, "img_feat"), (5, "flow_feat"))
+    errs = {f"G0.{n}": _rel(c[i], c_ref[i]) for i, n in names}
+    errs.update({f"G1.{n}": _rel(f[i], f_ref[i]) for i, n in names})
+    assert f[0].shape == (1, 3, H, W) and f[4].shape == (1, 64, H, W) and torch.isfinite(f[0]).all()
+    return errs, t_cpu
+
+
+def test_config2_two_scale_generator_full_size_bf16(dev):
+    errs, t_cpu = _two_scale(dev, 512, 1024, torch.bfloat16)
+    print("config 2 (512x1024, bf16) vs fp32 oracle:", {k: round(v, 5) for k, v in errs.items()}, f"CPU oracle {t_cpu:.1f} s")
+    assert all(v <= TOL[torch.bfloat16] for v in errs.values()), errs
+
+
+def test_config5_two_scale_generator_full_size_f16(dev):
+    errs, t_cpu = _two_scale(dev, 1024, 2048, torch.float16)
+    print("config 5 (1024x2048, f16) vs fp32 oracle:", {k: round(v, 5) for k, v in errs.items()}, f"CPU oracle {t_cpu:.1f} s")
+    assert all(v <= TOL[torch.float16] for v in errs.values()), errs
+    assert torch.cuda.max_memory_allocated(dev) < 60e9
