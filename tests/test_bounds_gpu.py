@@ -1,0 +1,162 @@
+"""Guard-band test of the kernels' addressing (a memory access fault was on record for a
+revision whose convolutions staged operands with flat ``global_load_lds`` and whose weight gradients went through MIOpen;
+DESIGN.md section 11 has the analysis).  Today's kernels stage through buffer resources with exact extents -- an
+out-of-range lane reads zeros and cannot fault -- and everything else is plain loads behind explicit bounds.  This test
+checks both halves of that claim without provoking a fault:
+
+* every INPUT lives inside a larger allocation whose neighbourhood (64 KB before and after) is NaN: a kernel that reads
+  outside its operand and lets the value reach a result produces NaN / a different result;
+* every OUTPUT lives inside a larger allocation whose neighbourhood holds a canary pattern: a kernel that writes outside
+  its result changes a canary.
+
+Results must be bit-identical to the same call on ordinary tensors.  Shapes are chosen so that tiles overhang every
+edge (pixel counts and channel counts that are not multiples of the tile sizes, last workgroup mostly empty).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GUARD = 32768     # elements on each side
+
+
+class Guarded:
+    """A tensor of ``shape`` (channels_last if 4-D and ``nhwc``) inside a guard-banded allocation."""
+
+    def __init__(self, like, fill):
+        t = like.detach()
+        self.nhwc = t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous()
+        n = t.numel()
+        self.buf = torch.full((n + 2 * GUARD,), fill, dtype=t.dtype, device=t.device)
+        core = self.buf[GUARD:GUARD + n]
+        if self.nhwc:
+            N, C, H, W = t.shape
+            self.t = core.view(N, H, W, C).permute(0, 3, 1, 2)
+        else:
+            self.t = core.view(t.shape)
+        self.t.copy_(t)
+        self.fill = fill
+
+    def intact(self):
+        lo, hi = self.buf[:GUARD], self.buf[-GUARD:]
+        if self.fill != self.fill:      # NaN
+            return bool(torch.isnan(lo).all() and torch.isnan(hi).all())
+        return bool((lo == self.fill).all() and (hi == self.fill).all())
+
+
+def _nhwc(n, c, h, w, dtype, dev, gen):
+    return torch.randn(n, c, h, w, generator=gen).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+
+
+CONV_CASES = {
+    # name: (N, Cin, H, W, Cout, k, stride, pad, pad_mode, transposed, output_padding)
+    "patch3x3_reflect_overhang": (1, 256, 37, 67, 256, 3, 1, 1, 1, False, 0),
+    "igemm3x3_zero_small_cin": (2, 64, 19, 23, 192, 3, 1, 1, 0, False, 0),
+    "d4x4_s2_p2": (1, 64, 33, 65, 128, 4, 2, 2, 0, False, 0),
+    "down3x3_s2": (1, 128, 21, 35, 256, 3, 2, 1, 0, False, 0),
+    "up3x3_transposed": (1, 256, 9, 13, 128, 3, 2, 1, 0, True, 1),
+    "head1x7_reflect": (1, 128, 11, 29, 24, (1, 7), 1, (0, 3), 1, False, 0),
+}
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("name", list(CONV_CASES))
+def test_convolution_forward_and_weight_gradient_stay_in_bounds(dev, name, dtype):
+    from ir2rgb_amd import conv as C
+    n, cin, h, w, cout, k, stride, pad, pad_mode, transposed, op = CONV_CASES[name]
+    gen = torch.Generator().manual_seed(len(name))
+    x = _nhwc(n, cin, h, w, dtype, dev, gen)
+    kk = C._pair(k)
+    wshape = (cin, cout) + kk if transposed else (cout, cin) + kk
+    wt = (torch.randn(wshape, generator=gen) * 0.05).to(dev)
+    bias = torch.randn(cout, generator=gen).to(dev)
+    desc = C.make_desc(tuple(x.shape), cout, k, stride, pad, pad_mode, dtype, transposed, op, out_f32=(cout % 8 != 0 or name.startswith("head")))
+    wp = C.pack_weight(desc, wt)
+    y0, s0 = C.conv2d_fwd(desc, x, wp, bias, want_stats=True)
+    gx, gw, gb = Guarded(x, float("nan")), Guarded(wp, float("nan")), Guarded(bias, float("nan"))
+    gy = Guarded(y0, 7.0)
+    gy.t.zero_()
+    y1, s1 = C.conv2d_fwd(desc, gx.t, gw.t, gb.t, want_stats=True, out=gy.t)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y1.float()).all() and torch.equal(y1, y0) and torch.equal(s1, s0)
+    assert gy.intact(), "convolution wrote outside its output"
+    assert gx.intact() and gw.intact() and gb.intact()
+    if name.startswith("head"):
+        return
+    g = _nhwc(n, cout, y0.shape[2], y0.shape[3], dtype, dev, gen)
+    dw0 = C.conv2d_wgrad(desc, x, g)
+    gg = Guarded(g, float("nan"))
+    dw1 = C.conv2d_wgrad(desc, gx.t, gg.t)
+    torch.cuda.synchronize()
+    assert torch.isfinite(dw1).all() and torch.equal(dw1, dw0)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_reflect_adjoint_stays_in_bounds(dev, dtype):
+    from ir2rgb_amd import conv as C
+    gen = torch.Generator().manual_seed(3)
+    gyv = _nhwc(1, 256, 37, 67, dtype, dev, gen)
+    wt = (torch.randn(256, 256, 3, 3, generator=gen) * 0.03).to(dev)
+    dadj = C.make_desc(gyv.shape, 256, 3, 1, 1, C.PAD_REFLECT_ADJ, dtype)
+    if C.kernel_name(dadj) != "conv3x3_patch_kernel":
+        pytest.skip("patch-staged kernel not selected for this shape")
+    wp = C.pack_weight(C.make_desc(gyv.shape, 256, 3, 1, 1, C.PAD_ZERO, dtype), wt, adjoint=True)
+    d0, _ = C.conv2d_fwd(dadj, gyv, wp)
+    gi, gw = Guarded(gyv, float("nan")), Guarded(wp, float("nan"))
+    go = Guarded(d0, 7.0)
+    d1, _ = C.conv2d_fwd(dadj, gi.t, gw.t, out=go.t)
+    torch.cuda.synchronize()
+    assert torch.isfinite(d1.float()).all() and torch.equal(d1, d0) and go.intact()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_batchnorm_kernels_stay_in_bounds(dev, dtype):
+    from ir2rgb_amd import autograd as A
+    from ir2rgb_amd import layers as L
+    gen = torch.Generator().manual_seed(5)
+    y = _nhwc(1, 128, 37, 53, dtype, dev, gen)
+    r1 = _nhwc(1, 128, 37, 53, dtype, dev, gen)
+    scale, shift = torch.rand(128, generator=gen).to(dev) + 0.5, torch.randn(128, generator=gen).to(dev)
+    mean, invstd = torch.randn(128, generator=gen).to(dev) * 0.1, torch.rand(128, generator=gen).to(dev) + 0.5
+    z0 = L.bn_apply(y, scale, shift, L.ACT_RELU, r1)
+    gyv, gr, gs, gh = Guarded(y, float("nan")), Guarded(r1, float("nan")), Guarded(scale, float("nan")), Guarded(shift, float("nan"))
+    gz = Guarded(z0, 7.0)
+    z1 = L.bn_apply(gyv.t, gs.t, gh.t, L.ACT_RELU, gr.t, out=gz.t)
+    torch.cuda.synchronize()
+    assert torch.equal(z1, z0) and gz.intact()
+    g = _nhwc(1, 128, 37, 53, dtype, dev, gen)
+    a0 = A.bn_bwd(g, y, scale, shift, mean, invstd, L.ACT_RELU)
+    gg, gm, gi = Guarded(g, float("nan")), Guarded(mean, float("nan")), Guarded(invstd, float("nan"))
+    a1 = A.bn_bwd(gg.t, gyv.t, gs.t, gh.t, gm.t, gi.t, L.ACT_RELU)
+    torch.cuda.synchronize()
+    for u, v in zip(a0, a1):
+        assert torch.isfinite(v.float()).all() and torch.equal(u, v)
+
+
+def test_operators_stay_in_bounds(dev):
+    """The three FlowNet2 operators and the warp-blend on guard-banded fp32 operands (flows that leave the image)."""
+    from ir2rgb_amd import ext
+    from ir2rgb_amd import layers as L
+    gen = torch.Generator().manual_seed(9)
+    img, flow = torch.rand(2, 3, 37, 53, generator=gen).to(dev), (torch.randn(2, 2, 37, 53, generator=gen) * 30).to(dev)
+    out0 = torch.zeros_like(img)
+    ext.resample2d_cuda.forward(img, flow, out0, 1)
+    gi, gf = Guarded(img, float("nan")), Guarded(flow, float("nan"))
+    go = Guarded(out0, 7.0)
+    go.t.zero_()
+    ext.resample2d_cuda.forward(gi.t, gf.t, go.t, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(go.t, out0) and go.intact() and torch.isfinite(out0).all()
+    raw, prev, wgt = torch.rand(2, 3, 37, 53, generator=gen).to(dev), torch.rand(2, 6, 37, 53, generator=gen).to(dev), \
+        torch.rand(2, 1, 37, 53, generator=gen).to(dev)
+    b0 = L.warp_blend(raw, prev, flow, wgt)
+    b1 = L.warp_blend(Guarded(raw, float("nan")).t, Guarded(prev, float("nan")).t, gf.t, Guarded(wgt, float("nan")).t)
+    torch.cuda.synchronize()
+    assert torch.equal(b0, b1) and torch.isfinite(b1).all()
+    f1, f2 = torch.randn(1, 32, 9, 13, generator=gen).to(dev), torch.randn(1, 32, 9, 13, generator=gen).to(dev)
+    from ir2rgb_amd.flownet2_pytorch.networks.correlation_package.correlation import Correlation
+    corr = Correlation(pad_size=20, kernel_size=1, max_displacement=20, stride1=1, stride2=2, corr_multiply=1)
+    c0 = corr(f1, f2)
+    c1 = corr(Guarded(f1, float("nan")).t, Guarded(f2, float("nan")).t)
+    torch.cuda.synchronize()
+    assert torch.equal(c0, c1) and torch.isfinite(c1).all()

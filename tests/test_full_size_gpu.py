@@ -6,9 +6,12 @@ the reference's graph in plain torch, pinned by the reference goldens), evaluate
 
 Same seeded reference init on both sides (bit-identical parameters: tests/test_networks_cpu.py), same smooth synthetic
 frames, train-mode BatchNorm, the coarse scale's features fed to the fine scale exactly as generator.py:139-160 chains
-them.  Bounds: relative L2 per tensor <= 2e-2 for bf16 and <= 5e-3 for f16.  At these sizes BatchNorm
-averages over 2 048 .. 2 M pixels, so the half-precision path sits well inside them (the 32x64 goldens of
-tests/test_networks_gpu.py, BatchNorm over 32 pixels, need 4e-2 for bf16).  img_final is not compared: random-init flow
+them.  Bounds, relative L2 per tensor: f16 <= 5e-3 (measured <= 3.3e-3 at both sizes); bf16 <= 3e-2 (measured 0.8e-2 ..
+2.6e-2).  SURVEY section 8d guessed 2e-2 for bf16; what 40 stages of bf16 STORAGE cost is ~sqrt(3 roundings x 40 stages)
+x 2^-9 x the gain of a BatchNorm stage ~ 2.5e-2, at any image size -- the independent rounding emulation
+(oracle/emulated.py, CPU) lands at the same distance from the fp32 goldens as the HIP path does
+(tests/test_oracle_networks.py, tests/test_harness_gpu.py), and the f16 run of the same configuration, 8x finer, sits at
+3e-3: the graph is exact, the distance is the storage format.  img_final is not compared: random-init flow
 heads emit +-40 px flows and the blend amplifies their 1e-3 differences (tests/test_networks_gpu.py checks the blend).
 """
 import copy
@@ -21,7 +24,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 OPT = dict(gen_blocks=9, n_blocks_local=3, fg=False, no_flow=False, n_local_enhancers=1, feat_num=3)
-TOL = {torch.bfloat16: 2e-2, torch.float16: 5e-3}
+TOL = {torch.bfloat16: 3e-2, torch.float16: 5e-3}
 
 
 def _smooth(shape, seed):
@@ -35,7 +38,7 @@ def _rel(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
 
 
-def _two_scale(dev, H, W, dtype):
+def _two_scale(dev, H, W, dtypes):
     from ir2rgb_amd import networks as N
     from oracle import networks_oracle as NO
     torch.manual_seed(0)
@@ -51,26 +54,31 @@ def _two_scale(dev, H, W, dtype):
         f_ref = NO.generator_forward(r1, A, P, c_ref[4], c_ref[5])
     t_cpu = time.time() - t0
     g0, g1 = g0.to(dev), g1.to(dev)
-    g0.compute_dtype = g1.compute_dtype = dtype
-    with torch.no_grad():
-        c = g0(A0.to(dev), P0.to(dev), None, None, None, None, False)
-        f = g1(A.to(dev), P.to(dev), None, c[4], c[5], None, False)
-    torch.cuda.synchronize()
-    names = ((1, "flow"), (2, "weight"), (3, "img_raw"), (4, "img_feat"), (5, "flow_feat"))
-    errs = {f"G0.{n}": _rel(c[i], c_ref[i]) for i, n in names}
-    errs.update({f"G1.{n}": _rel(f[i], f_ref[i]) for i, n in names})
-    assert f[0].shape == (1, 3, H, W) and f[4].shape == (1, 64, H, W) and torch.isfinite(f[0]).all()
-    return errs, t_cpu
+    out = {}
+    for dtype in dtypes:
+        g0.compute_dtype = g1.compute_dtype = dtype
+        with torch.no_grad():
+            c = g0(A0.to(dev), P0.to(dev), None, None, None, None, False)
+            f = g1(A.to(dev), P.to(dev), None, c[4], c[5], None, False)
+        torch.cuda.synchronize()
+        names = ((1, "flow"), (2, "weight"), (3, "img_raw"), (4, "img_feat"), (5, "flow_feat"))
+        errs = {f"G0.{n}": _rel(c[i], c_ref[i]) for i, n in names}
+        errs.update({f"G1.{n}": _rel(f[i], f_ref[i]) for i, n in names})
+        assert f[0].shape == (1, 3, H, W) and f[4].shape == (1, 64, H, W) and torch.isfinite(f[0]).all()
+        out[dtype] = errs
+    return out, t_cpu
 
 
-def test_config2_two_scale_generator_full_size_bf16(dev):
-    errs, t_cpu = _two_scale(dev, 512, 1024, torch.bfloat16)
-    print("config 2 (512x1024, bf16) vs fp32 oracle:", {k: round(v, 5) for k, v in errs.items()}, f"CPU oracle {t_cpu:.1f} s")
-    assert all(v <= TOL[torch.bfloat16] for v in errs.values()), errs
+def test_config2_two_scale_generator_full_size(dev):
+    res, t_cpu = _two_scale(dev, 512, 1024, (torch.bfloat16, torch.float16))
+    for dtype, errs in res.items():
+        print(f"config 2 (512x1024, {dtype}) vs fp32 oracle:", {k: round(v, 5) for k, v in errs.items()}, f"CPU oracle {t_cpu:.1f} s")
+        assert all(v <= TOL[dtype] for v in errs.values()), (dtype, errs)
 
 
 def test_config5_two_scale_generator_full_size_f16(dev):
-    errs, t_cpu = _two_scale(dev, 1024, 2048, torch.float16)
+    res, t_cpu = _two_scale(dev, 1024, 2048, (torch.float16,))
+    errs = res[torch.float16]
     print("config 5 (1024x2048, f16) vs fp32 oracle:", {k: round(v, 5) for k, v in errs.items()}, f"CPU oracle {t_cpu:.1f} s")
     assert all(v <= TOL[torch.float16] for v in errs.values()), errs
     assert torch.cuda.max_memory_allocated(dev) < 60e9
