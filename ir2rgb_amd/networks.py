@@ -87,9 +87,12 @@ class ResnetBlock(nn.Module):
                                 norm_layer(dim)])
 
     def run(self, x, extra_residual=None):
-        """NHWC half in/out; ``extra_residual`` is added to the block output (encoder sum)."""
+        """NHWC half in/out; ``extra_residual`` is added to the block output (encoder sum).  It may be a callable
+        returning the tensor: it is called as late as possible (a branch computed on another stream is joined there)."""
         cb, tr, dt = self.conv_block, self.training, x.dtype
         h = A.conv_stage(x, cb[1], cb[2], L.ACT_RELU, C.PAD_REFLECT, dt, pad=1, training=tr)
+        if callable(extra_residual):
+            extra_residual = extra_residual()
         return A.conv_stage(h, cb[5], cb[6], L.ACT_NONE, C.PAD_REFLECT, dt, pad=1, res1=x, res2=extra_residual,
                             training=tr)
 
@@ -160,20 +163,79 @@ def _real(x, channels):
     return x[:, :channels].contiguous(memory_format=torch.channels_last)
 
 
+# ---------------------------------------------------------------------------------------------
+# independent branches on two HIP streams.  The composite generators are two chains twice over: the label encoder
+# and the previous-frame encoder (networks.py:192 / :290 sums them), then the image decoder and the flow decoder
+# (:193-201 / :291-299).  One chain alone alternates chip-filling convolutions with BatchNorm statistics / apply
+# kernels that are a few MB of traffic behind a dependent launch -- the chip idles through a fifth of the time.  Two
+# chains on two streams fill each other's gaps (the convolutions are MFMA-bound, the BatchNorm passes HBM- and
+# latency-bound).  Results are unchanged (same kernels, same operands).  torch.autograd replays every node on the
+# stream its forward ran on, so loss.backward() overlaps the same way; HIP-graph capture records the fork / join.
+# ---------------------------------------------------------------------------------------------
+import os as _os
+
+BRANCH_STREAMS = _os.environ.get("IR2RGB_BRANCH_STREAMS", "1") != "0"
+_SIDE_STREAMS = {}
+
+
+class _Branch:
+    """``with _Branch(x) as b: y = f(x)`` runs the body on the device's side stream after everything queued on the
+    current stream; ``b.join(y, ...)`` makes the current stream wait for it and returns the tensors."""
+
+    def __init__(self, *inputs):
+        self.inputs = [t for t in inputs if isinstance(t, torch.Tensor)]
+        self.enabled = BRANCH_STREAMS and bool(self.inputs) and self.inputs[0].is_cuda
+        self.ctx = None
+
+    def __enter__(self):
+        if self.enabled:
+            dev = self.inputs[0].device
+            self.main = torch.cuda.current_stream(dev)
+            self.side = _SIDE_STREAMS.get(dev.index)
+            if self.side is None:
+                self.side = _SIDE_STREAMS[dev.index] = torch.cuda.Stream(dev)
+            self.side.wait_stream(self.main)
+            for t in self.inputs:
+                t.record_stream(self.side)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+            self.ctx = None
+        return False
+
+    def join(self, *outs):
+        if self.enabled:
+            self.main.wait_stream(self.side)
+            for t in outs:
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(self.main)
+            self.enabled = False
+        return outs[0] if len(outs) == 1 else outs
+
+
 class _CompositeBase(nn.Module):
     compute_dtype = torch.bfloat16
 
-    def _heads_and_blend(self, img_feat, flow_feat, img_prev, use_raw_only, flow_mul):
-        img_raw = A.head_stage(img_feat, [self.model_final_img[1]], [1] * self.model_final_img[1].out_channels)
+    def _img_head(self, img_feat):
+        return A.head_stage(img_feat, [self.model_final_img[1]], [1] * self.model_final_img[1].out_channels)
+
+    def _flow_heads(self, flow_feat, flow_mul):
+        """flow (x flow_mul) and weight (sigmoid) heads evaluated as one separable convolution: [N,3,H,W] fp32."""
+        return A.head_stage(flow_feat, [self.model_final_flow[1], self.model_final_w[1]], [0, 0, 2], mul=flow_mul)
+
+    def _blend(self, img_raw, fw, img_prev, use_raw_only):
         flow = weight = None
-        if not self.no_flow:
-            fw = A.head_stage(flow_feat, [self.model_final_flow[1], self.model_final_w[1]], [0, 0, 2], mul=flow_mul)
+        if fw is not None:
             flow, weight = fw[:, 0:2], fw[:, 2:3]
         if use_raw_only or self.no_flow:
             img_final = img_raw
         else:
             img_final = A.warp_blend(img_raw, img_prev.float(), flow, weight)
-        return img_final, flow, weight, img_raw
+        return img_final, flow, weight
 
     @staticmethod
     def _check_inputs(input, img_prev):
@@ -223,13 +285,18 @@ class CompositeGeneratorModule(_CompositeBase):
     def forward(self, input, img_prev, mask, img_feat_coarse, flow_feat_coarse, img_fg_feat_coarse, use_raw_only):
         self._check_inputs(input, img_prev)
         dt, tr = self.compute_dtype, self.training
-        seg = _run_sequence(self.model_down_seg, input, dt, tr)
-        downsample = _run_sequence(self.model_down_img, img_prev, dt, tr, final_residual=seg)  # seg + img (:192)
+        with _Branch(input) as enc:                          # the label encoder beside the previous-frame encoder
+            seg = _run_sequence(self.model_down_seg, input, dt, tr)
+        downsample = _run_sequence(self.model_down_img, img_prev, dt, tr, final_residual=lambda: enc.join(seg))  # (:192)
+        flow_feat = fw = None
+        with _Branch(downsample) as dec:                     # the flow decoder + its heads beside the image decoder
+            if not self.no_flow:
+                flow_feat = _run_sequence(self.model_up_flow, _run_sequence(self.model_res_flow, downsample, dt, tr), dt, tr)
+                fw = self._flow_heads(flow_feat, 20.0)
         img_feat = _run_sequence(self.model_up_img, _run_sequence(self.model_res_img, downsample, dt, tr), dt, tr)
-        flow_feat = None
-        if not self.no_flow:
-            flow_feat = _run_sequence(self.model_up_flow, _run_sequence(self.model_res_flow, downsample, dt, tr), dt, tr)
-        img_final, flow, weight, img_raw = self._heads_and_blend(img_feat, flow_feat, img_prev, use_raw_only, 20.0)
+        img_raw = self._img_head(img_feat)
+        dec.join(flow_feat, fw)
+        img_final, flow, weight = self._blend(img_raw, fw, img_prev, use_raw_only)
         L.flush_bn_counters()
         return img_final, flow, weight, img_raw, _real(img_feat, self.ngf), _real(flow_feat, self.ngf), None
 
@@ -263,22 +330,28 @@ class CompositeLocalGeneratorModule(_CompositeBase):
     def _encode(self, seq, x, dt, tr, res1=None):
         mods = list(seq)
         h = A.conv_stage(x, mods[1], mods[2], L.ACT_RELU, C.PAD_REFLECT, dt, first=True, pad=3, training=tr)
+        if callable(res1):      # the other encoder ran on the side stream: joined as late as possible
+            res1 = res1()
         # the stride-2 stage ends the encoder: the other encoder's output is added in its epilogue pass
         return A.conv_stage(h, mods[4], mods[5], L.ACT_RELU, C.PAD_ZERO, dt, res1=res1, training=tr)
 
     def forward(self, input, img_prev, mask, img_feat_coarse, flow_feat_coarse, img_fg_feat_coarse, use_raw_only):
         self._check_inputs(input, img_prev)
         dt, tr = self.compute_dtype, self.training
-        seg = self._encode(self.model_down_seg, input, dt, tr)
-        down_img = self._encode(self.model_down_img, img_prev, dt, tr, res1=seg)                   # (:290)
+        with _Branch(input) as enc:
+            seg = self._encode(self.model_down_seg, input, dt, tr)
+        down_img = self._encode(self.model_down_img, img_prev, dt, tr, res1=lambda: enc.join(seg))  # (:290)
+        flow_feat = fw = None
+        with _Branch(down_img, flow_feat_coarse) as dec:
+            if not self.no_flow:
+                flow_in = A.add(down_img, _padded(A.to_nhwc_half(flow_feat_coarse, dt)))   # (:297)
+                flow_feat = _run_sequence(self.model_up_flow, flow_in, dt, tr)
+                fw = self._flow_heads(flow_feat, 20.0 * (2 ** self.scale))
         img_in = A.add(down_img, _padded(A.to_nhwc_half(img_feat_coarse, dt)))             # (:291)
         img_feat = _run_sequence(self.model_up_img, img_in, dt, tr)
-        flow_feat = None
-        if not self.no_flow:
-            flow_in = A.add(down_img, _padded(A.to_nhwc_half(flow_feat_coarse, dt)))       # (:297)
-            flow_feat = _run_sequence(self.model_up_flow, flow_in, dt, tr)
-        img_final, flow, weight, img_raw = self._heads_and_blend(img_feat, flow_feat, img_prev, use_raw_only,
-                                                                 20.0 * (2 ** self.scale))
+        img_raw = self._img_head(img_feat)
+        dec.join(flow_feat, fw)
+        img_final, flow, weight = self._blend(img_raw, fw, img_prev, use_raw_only)
         L.flush_bn_counters()
         return img_final, flow, weight, img_raw, _real(img_feat, self.ngf), _real(flow_feat, self.ngf), None
 
