@@ -169,12 +169,16 @@ def _real(x, channels):
 # (:193-201 / :291-299).  One chain alone alternates chip-filling convolutions with BatchNorm statistics / apply
 # kernels that are a few MB of traffic behind a dependent launch -- the chip idles through a fifth of the time.  Two
 # chains on two streams fill each other's gaps (the convolutions are MFMA-bound, the BatchNorm passes HBM- and
-# latency-bound).  Results are unchanged (same kernels, same operands).  torch.autograd replays every node on the
-# stream its forward ran on, so loss.backward() overlaps the same way; HIP-graph capture records the fork / join.
+# latency-bound).  Results are unchanged (same kernels, same operands).  HIP-graph capture records the fork / join.
+# Measured on the 512x1024 single-scale forward (tools/prof_forward.py --graph): 7.07 -> 6.61 ms.
+# IR2RGB_BRANCH_STREAMS: "auto" (default) = forwards without autograd (inference, the north-star forward); "1" = also
+# under autograd (torch.autograd replays every node on the stream its forward ran on, so loss.backward() overlaps the
+# same way: 37.4 -> 36.4 ms per training window, but then no convolution of the step runs alone any more and a
+# per-kernel duration measured in place -- bench.py's roofline leg -- times two kernels sharing the chip); "0" = never.
 # ---------------------------------------------------------------------------------------------
 import os as _os
 
-BRANCH_STREAMS = _os.environ.get("IR2RGB_BRANCH_STREAMS", "1") != "0"
+BRANCH_STREAMS = _os.environ.get("IR2RGB_BRANCH_STREAMS", "auto")
 _SIDE_STREAMS = {}
 
 
@@ -184,7 +188,8 @@ class _Branch:
 
     def __init__(self, *inputs):
         self.inputs = [t for t in inputs if isinstance(t, torch.Tensor)]
-        self.enabled = BRANCH_STREAMS and bool(self.inputs) and self.inputs[0].is_cuda
+        on = BRANCH_STREAMS == "1" or (BRANCH_STREAMS == "auto" and not torch.is_grad_enabled())
+        self.enabled = on and bool(self.inputs) and self.inputs[0].is_cuda
         self.ctx = None
 
     def __enter__(self):

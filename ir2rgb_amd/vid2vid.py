@@ -281,6 +281,15 @@ class Vid2VidTrainer:
         self.repacker = layers.WeightRepacker(list(self.netG) + [self.netD] + list(self.netD_T)) if o["batched_repack"] else None
         self.reset_sequence()
 
+    def _flow_stream(self, t):
+        """The side stream FlowNet2 runs on (None: same stream as everything else; IR2RGB_FLOW_STREAM=0 or CPU tensors)."""
+        import os
+        if not t.is_cuda or os.environ.get("IR2RGB_FLOW_STREAM", "1") == "0":
+            return None
+        if getattr(self, "_flow_side", None) is None:
+            self._flow_side = torch.cuda.Stream(t.device)
+        return self._flow_side
+
     # ------------------------------------------------------------------ per-sequence state
     def reset_sequence(self):
         self.fake_B_prev = None          # pyramid of the last tG-1 generated frames
@@ -533,9 +542,25 @@ class Vid2VidTrainer:
         ``D_T{s}`` and every term under the reference's names (``G_GAN`` ... ``W``; temporal ones with the scale
         appended, ``G_T_GAN0`` ...).  ``self.last_outputs`` keeps (fake_B, fake_B_raw, flow, weight), detached."""
         fake_prev_last = self.fake_B_prev
+        # The reference flows depend on real frames only (train_vid2vid.py:62-65 computes them after the generator, from
+        # real_Bp = input_B[:, tG-2:]): FlowNet2 -- a few hundred small launches, frozen, no autograd -- runs on a second
+        # HIP stream BESIDE the generator forward and is joined before the losses that read its result.
+        tG = self.opt["n_input_gen_frames"]
+        real_Bp_in = input_B[:, tG - 2:]
+        side = self._flow_stream(input_B)
+        if side is not None:
+            main = torch.cuda.current_stream(input_B.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                flow_ref, conf_ref, rb_s, extra_flows = self.reference_flows(real_Bp_in[:, 1:], real_Bp_in[:, :-1])
         fake_B, fake_B_raw, flow, weight, real_A, real_Bp = self.generate(input_A, input_B)
         real_B_prev, real_B = real_Bp[:, :-1], real_Bp[:, 1:]
-        flow_ref, conf_ref, rb_s, extra_flows = self.reference_flows(real_B, real_B_prev)
+        if side is not None:
+            main.wait_stream(side)
+            for t in [flow_ref, conf_ref] + [x for pair in extra_flows.values() for x in pair] + [x for x in rb_s if x is not None]:
+                t.record_stream(main)
+        else:
+            flow_ref, conf_ref, rb_s, extra_flows = self.reference_flows(real_B, real_B_prev)
         # compute_fake_B_prev (generator.py:283-287) AS THE REFERENCE'S LOOP EVALUATES IT.  train_vid2vid.py:60,:67-68
         # hands the previous window's pyramid LIST to model_g and afterwards to compute_fake_B_prev; in between,
         # generate_frame_train appends the new frames to the elements of that very list (generator.py:113, :175:
