@@ -14,8 +14,9 @@ Prints ONE JSON line (rank 0).  Besides the contract keys it carries
   roofline     -- the dominant kernel (MFMA implicit-GEMM 3x3 convolution), HIP-event timed per launch
                   inside the timed region on the launch stream: algorithmic flops / mean duration
                   against the 2.5 PFLOP/s dense bf16 peak (MI355X_MICROARCH.md);
-  cpu_baseline -- the plain-torch fp32 port of the same two-scale generator (oracle/networks_oracle.py)
-                  timed on the host cores, rank 0 at N=1 only, on a bounded sample;
+  cpu_baseline -- the plain-torch fp32 restatement of the single-scale generator (oracle/networks_oracle.py), forward
+                  and forward+backward at 512x1024 on the host cores (median of 3, CPU model and core count stated),
+                  rank 0 at N=1 only;
   extra        -- generator-forward timings incl. the north-star 512x1024 single-scale forward.
 """
 import argparse
@@ -49,27 +50,54 @@ def usable_cpus():
     return max(1, min(n, 64))
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(threads):
-    """Plain-torch fp32 port of the 2-scale generator forward on the host, one frame (bounded sample)."""
+    """the plain-torch fp32 restatement of the single-scale CompositeGenerator(ngf 128) -- the
+    reference's graph (oracle/networks_oracle.py, pinned by the reference goldens) -- at 512x1024 on the host cores:
+    forward, and forward + backward, median of 3 after one warm-up forward.  A bounded sample (one frame per run) of the
+    generator part of the workload; the GPU metric additionally runs FlowNet2, the discriminators and Adam."""
     from ir2rgb_amd import networks as N
     from oracle import networks_oracle as NO
     torch.set_num_threads(threads)
     opt = dict(gen_blocks=9, n_blocks_local=3, fg=False, no_flow=False, n_local_enhancers=1, feat_num=3)
     torch.manual_seed(0)
-    g0 = N.build_generator_module(9, 3, 6, 128, "composite", 3, "batch", 0, **opt).train()
-    g1 = N.build_generator_module(9, 3, 6, 64, "composite-local", 3, "batch", 1, **opt).train()
+    g = N.build_generator_module(9, 3, 6, 128, "composite", 3, "batch", 0, **opt).train()
     gen = torch.Generator().manual_seed(1)
     A = torch.tanh(torch.randn(1, 9, H, W, generator=gen))
     P = torch.tanh(torch.randn(1, 6, H, W, generator=gen))
-    A0, P0 = torch.nn.functional.avg_pool2d(A, 2), torch.nn.functional.avg_pool2d(P, 2)
-    with torch.no_grad():
+
+    def fwd():
+        with torch.no_grad():
+            t0 = time.time()
+            NO.generator_forward(g, A, P)
+            return time.time() - t0
+
+    def fwd_bwd():
         t0 = time.time()
-        r0 = NO.generator_forward(g0, A0, P0)
-        NO.generator_forward(g1, A, P, r0[4], r0[5])
+        out = NO.generator_forward(g, A, P)
+        (out[0].mean() + out[1].abs().mean() * 0.01 + out[2].mean()).backward()
         dt = time.time() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": "1 frame: fp32 plain-torch port of the 2-scale generator FORWARD only (2.27 TFLOP) at 512x1024, "
-                      f"{dt:.1f} s; the GPU metric additionally runs FlowNet2, the discriminators, backward and Adam"}
+        g.zero_grad(set_to_none=True)
+        return dt
+
+    fwd()                                                  # warm-up (thread pool, allocator, oneDNN primitives)
+    t_f = sorted(fwd() for _ in range(3))[1]
+    t_fb = sorted(fwd_bwd() for _ in range(3))[1]
+    return {"value": round(1.0 / t_fb, 4), "unit": "frames/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
+            "forward_s": round(t_f, 2), "forward_backward_s": round(t_fb, 2), "forward_TFLOPs": round(6.632 / t_f, 3),
+            "sample": "1 frame per run, median of 3: fp32 plain-torch restatement of CompositeGenerator(ngf 128, 3 down, 9 blocks) "
+                      f"at 512x1024 (6.63 TFLOP forward): forward {t_f:.1f} s, forward+backward {t_fb:.1f} s (value = 1 / the "
+                      "latter); the GPU metric additionally runs the second spatial scale, FlowNet2, the discriminators, "
+                      "their backward passes and Adam"}
 
 
 def main():
