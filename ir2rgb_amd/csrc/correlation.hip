@@ -16,9 +16,15 @@
 //   * the lane quarters are combined with two wave64 xor-shuffles (lanes^16, ^32), the channel
 //     halves through LDS; every lane quarter then stores its share of the rows as 32-byte runs
 //     (512 B contiguous per row per wave).
+// corr_fwd_lds (below) is that design with its operands staged through LDS by LDS-DMA and packed FMAs.
 // A generic one-lane-per-output kernel covers every other parameter set.
+// Backward (corr_bwd_kernel): one lane per input element, API completeness only -- FlowNet2 runs under no_grad on
+// this path (models/flownet.py:21), so it is NOT a performance kernel (2.8 ms at the config-3 size).
 //
 // Algorithmic bytes (forward) = 4*N*(2*C*H*W + outC*outH*outW); flops = 2*N*outC*outH*outW*k*k*C.
+#include <type_traits>
+#include <utility>
+
 #include "common.h"
 
 static void out_shape(int H, int W, int pad, int ksize, int md, int s1, int s2, int *oc, int *oh, int *ow) {
@@ -150,6 +156,191 @@ corr_fwd_tile(const float *__restrict__ f1, const float *__restrict__ f2, float 
 }
 
 // ----------------------------------------------------------------------------------------
+// LDS-staged forward path (the default for the FlowNetC configuration; corr_fwd_tile above stays as the
+// fallback for channel counts that are not multiples of 8 and as the A/B reference, IR2RGB_CORR_LDS=0).
+//
+// corr_fwd_tile feeds its FMAs straight from L2: per channel a lane issues 10 global_load_dwordx4 for 96 FMAs,
+// and the texture path hands a CU 64 B per clock -- 16 clocks per 1 KB wave-load, ~39 us of load issue chip-wide
+// for the [1,256,64,128] volume: that, not the 12 us of FMAs, set its 74 us.  Here the same register tile (a lane
+// keeps 8 pixels x <= 12 displacements, the 4 waves of a workgroup = 2 displacement halves x 2 channel halves,
+// the 4 lane quarters interleave channels) is fed from LDS, which serves a 1 KB ds_read_b128 in 4 clocks:
+//   * operands arrive by LDS-DMA (buffer_load ... lds: no VGPR round trip, per-lane 32-bit source offsets computed
+//     once, the channel-group offset rides in an SGPR; out-of-row columns are out-of-range buffer offsets = zeros,
+//     which IS the zero padding): one stage = 8 channels of the f1 row chunk (8 x 128 floats) and of the f2 row
+//     window (8 x 176 floats, halo 20 left / 28 right), 11 one-KB DMA instructions, three stages in flight;
+//   * rows of odd lane quarters are stored one 16-byte slot to the right: the 16 lanes a ds_read_b128 serves per
+//     clock ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ... : two quarters at a time, MI355X_MICROARCH.md LDS) then
+//     touch 16 distinct 16-byte bank windows (even ones for one quarter, odd ones for the other);
+//   * the FMAs are packed: a pixel pair times a pixel pair of the shifted window (stride2 = 2 shifts by whole
+//     pairs), v_pk_fma_f32 -- 48 instructions per channel instead of 96.
+// One s_barrier + one counted vmcnt per 8-channel stage.  Reduction and stores as in corr_fwd_tile.
+// ----------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(2))) float corr_f2;
+typedef __attribute__((address_space(3))) void *corr_lptr_t;
+#define CORR_OOB 0x80000000u
+
+template <int DR, int S2, int T0>
+__global__ void __launch_bounds__(256)
+corr_fwd_lds(const float *__restrict__ f1, const float *__restrict__ f2, float *__restrict__ out, int C, int H, int W,
+             int xchunks, float inv_nelems, unsigned in_bytes) {
+    static_assert(S2 == 2, "packed form: a displacement step shifts the window by one pixel pair");
+    constexpr int D = 2 * DR + 1;
+    constexpr int TMAX = T0 > D - T0 ? T0 : D - T0;
+    constexpr int HALO = S2 * DR;                       // 20
+    constexpr int NB = 8 + S2 * (TMAX - 1), NB4 = (NB + 3) / 4;   // 30 floats -> 8 chunks per lane and channel
+    constexpr int F1P = 40, F2P = 48;                   // row pitches in 16-byte slots (32 / 44 data chunks + shift + pad)
+    constexpr int F2C = 44;                             // data chunks of an f2 row: x in [x_chunk - 20, x_chunk + 156)
+    constexpr int F1S = 8 * F1P, SLOTS = F1S + 8 * F2P; // 320 + 384 slots per stage: f1 ends on an instruction boundary
+    constexpr int NDMA = SLOTS / 64, NF1 = F1S / 64;    // 11 DMA instructions per stage, the first 5 read f1
+    constexpr int PERW = (NDMA + 3) / 4;                // 3 per wave (wave 3: its third is a dummy)
+    constexpr int STAGE = NDMA * 1024, NST = 4;         // four stages: three in flight while one is consumed
+    static_assert(HALO % 4 == 0 && (S2 * T0) % 4 == 0, "f2 windows must keep float4 alignment");
+    static_assert(F1S % 64 == 0 && SLOTS % 64 == 0, "regions must end on DMA instruction boundaries");
+    constexpr int RED = 2 * TMAX * 8 * 64 * 4;          // reduction scratch (re-uses the ring after the last stage)
+    constexpr int RING = NST * STAGE > RED ? NST * STAGE : RED;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[RING + 1024];
+    unsigned char *const dummy = smem + RING;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int th = wave & 1, ch = wave >> 1;
+    // XCD-aware unit ids: workgroup b runs on XCD b % 8, and the eight L2s (4 MB each) do not share.  Units are
+    // numbered (n, y, tj, x chunk) with y slowest; giving XCD k the k-th contiguous eighth of them makes the units that
+    // read the same f1 row (all 21 tj of a y) and the same f2 row ((y, tj) and (y + 2, tj - 1)) neighbours in ONE L2:
+    // with round-robin ids every XCD streamed all 16.8 MB of both tensors through its own 4 MB.
+    long unit = blockIdx.x;
+    if ((gridDim.x & 7) == 0) unit = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int xc = (int)(unit % xchunks); unit /= xchunks;
+    const int tj = (int)(unit % D) - DR;  unit /= D;
+    const int y = (int)(unit % H);
+    const int n = (int)(unit / H);
+
+    const int t0 = th ? T0 : 0, nt = th ? D - T0 : T0;
+    const int xo = lane & 15, cs = lane >> 4;
+    const int x0 = xc * 128 + xo * 8;
+    const int y2 = y + tj * S2;
+    const bool row_ok = (y2 >= 0) && (y2 < H);       // workgroup-uniform
+    const bool lane_ok = x0 < W;
+    const long hw = (long)H * W;
+
+    corr_f2 acc[TMAX][4];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[t][k] = (corr_f2){0.f, 0.f};
+
+    if (row_ok) {
+        const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(f1), 0, (int)in_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(f2), 0, (int)in_bytes, 0x00020000);
+        // ---- per-lane DMA source offsets (bytes) of this wave's instructions: slot -> (tensor, row, chunk) ----
+        unsigned voff[PERW];
+#pragma unroll
+        for (int j = 0; j < PERW; ++j) {
+            const int id = wave + 4 * j;                 // wave-uniform instruction id
+            const int slot = id * 64 + lane;
+            unsigned v = CORR_OOB;
+            if (id < NF1) {
+                const int row = slot / F1P, pos = slot - row * F1P, chunk = pos - ((row >> 1) & 1);
+                const int x = xc * 128 + 4 * chunk;
+                if (chunk >= 0 && chunk < 32 && x + 3 < W)
+                    v = (unsigned)((((long)n * C + row) * hw + (long)y * W + x) * 4);
+            } else if (id < NDMA) {
+                const int s2 = slot - F1S, row = s2 / F2P, pos = s2 - row * F2P, chunk = pos - ((row >> 1) & 1);
+                const int x = xc * 128 - HALO + 4 * chunk;
+                if (chunk >= 0 && chunk < F2C && x >= 0 && x + 3 < W)
+                    v = (unsigned)((((long)n * C + row) * hw + (long)y2 * W + x) * 4);
+            }
+            voff[j] = v;
+        }
+        const int NG = C >> 3;
+        auto issue = [&](int g) {
+            const bool live = g < NG;                    // past the last stage: same instruction count, harmless target
+            unsigned char *dst = smem + (g % NST) * STAGE;
+            const unsigned soff = live ? (unsigned)((long)g * 8 * hw * 4) : 0u;
+#pragma unroll
+            for (int j = 0; j < PERW; ++j) {
+                const int id = wave + 4 * j;
+                if (id >= NDMA || !live) __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (corr_lptr_t)dummy, 16, CORR_OOB, 0, 0, 0);
+                else if (id < NF1) __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (corr_lptr_t)(dst + id * 1024), 16, voff[j], soff, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(r2, (corr_lptr_t)(dst + id * 1024), 16, voff[j], soff, 0, 0);
+            }
+        };
+        // ---- per-lane LDS read offsets: row = this lane's channel within the group of 8, shifted if cs is odd ----
+        const int row = 2 * cs + ch, rot = cs & 1;
+        const unsigned aofs = (unsigned)((row * F1P + rot + 2 * xo) * 16);
+        const unsigned bofs = (unsigned)((F1S + row * F2P + rot + 2 * xo + (S2 * t0) / 4) * 16);
+        auto run = [&]<int NT>(std::integral_constant<int, NT>) {
+            issue(0);
+            issue(1);
+            issue(2);
+            for (int g = 0; g < NG; ++g) {
+                // stages g+1, g+2 (2 * PERW instructions of this wave) may still be in flight; past the end the
+                // no-op stages keep the count uniform
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PERW) : "memory");
+                __builtin_amdgcn_s_barrier();            // stage g has landed for every wave; stage g-1 is consumed
+                issue(g + 3);
+                const unsigned char *st = smem + (g % NST) * STAGE;
+                corr_f2 a[4], b[NB4 * 2];
+                {
+                    const float4 u0 = *reinterpret_cast<const float4 *>(st + aofs), u1 = *reinterpret_cast<const float4 *>(st + aofs + 16);
+                    a[0] = (corr_f2){u0.x, u0.y}; a[1] = (corr_f2){u0.z, u0.w};
+                    a[2] = (corr_f2){u1.x, u1.y}; a[3] = (corr_f2){u1.z, u1.w};
+                }
+#pragma unroll
+                for (int j = 0; j < (8 + S2 * (NT - 1) + 3) / 4; ++j) {
+                    const float4 v = *reinterpret_cast<const float4 *>(st + bofs + 16 * j);
+                    b[2 * j] = (corr_f2){v.x, v.y};
+                    b[2 * j + 1] = (corr_f2){v.z, v.w};
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[t][k] = __builtin_elementwise_fma(a[k], b[k + t], acc[t][k]);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing no-op stages
+        };
+        if (th == 0) run(std::integral_constant<int, T0>{});
+        else run(std::integral_constant<int, D - T0>{});
+        __builtin_amdgcn_s_barrier();                // the ring is free: it becomes the reduction scratch
+    }
+
+    float (*red)[TMAX * 8][64] = reinterpret_cast<float (*)[TMAX * 8][64]>(smem);
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            corr_f2 v = acc[t][k];
+            v.x += __shfl_xor(v.x, 16, 64); v.y += __shfl_xor(v.y, 16, 64);
+            v.x += __shfl_xor(v.x, 32, 64); v.y += __shfl_xor(v.y, 32, 64);
+            acc[t][k] = v;
+        }
+    if (ch == 1) {
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { red[th][t * 8 + 2 * k][lane] = acc[t][k].x; red[th][t * 8 + 2 * k + 1][lane] = acc[t][k].y; }
+    }
+    __syncthreads();
+    if (ch == 0 && lane_ok) {
+        float *o = out + (((long)n * (D * D) + (long)(tj + DR) * D + t0) * H + y) * (long)W + x0;
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) {
+            if (t < nt && (t & 3) == cs) {
+                float r[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    r[2 * k] = (acc[t][k].x + red[th][t * 8 + 2 * k][lane]) * inv_nelems;
+                    r[2 * k + 1] = (acc[t][k].y + red[th][t * 8 + 2 * k + 1][lane]) * inv_nelems;
+                }
+                float4 *q = reinterpret_cast<float4 *>(o + (long)t * hw);
+                q[0] = make_float4(r[0], r[1], r[2], r[3]);
+                q[1] = make_float4(r[4], r[5], r[6], r[7]);
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------
 // generic forward: one lane per output element, any (pad, k, md, s1, s2)
 // ----------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
@@ -268,7 +459,13 @@ extern "C" int ir2rgb_correlation_fwd(const float *in1, const float *in2, float 
     if (fast) {
         int xchunks = cdiv(W, 128);
         long units = (long)N * H * 21 * xchunks;  // (n, y, tj, xchunk): one workgroup each
-        corr_fwd_tile<10, 2, 12><<<(unsigned)units, 256, 0, s>>>(in1, in2, out, C, H, W, xchunks, inv);
+        static int use_lds = -1;
+        if (use_lds < 0) { const char *e = getenv("IR2RGB_CORR_LDS"); use_lds = e ? atoi(e) : 1; }
+        const long in_bytes = (long)N * C * H * W * 4;
+        if (use_lds && (C % 8) == 0 && in_bytes < (1L << 31))
+            corr_fwd_lds<10, 2, 12><<<(unsigned)units, 256, 0, s>>>(in1, in2, out, C, H, W, xchunks, inv, (unsigned)in_bytes);
+        else
+            corr_fwd_tile<10, 2, 12><<<(unsigned)units, 256, 0, s>>>(in1, in2, out, C, H, W, xchunks, inv);
         return ir2rgb_launch_status();
     }
     corr_fwd_generic<<<stream_grid(total, 256), 256, 0, s>>>(in1, in2, out, C, H, W, pad_size,
