@@ -229,7 +229,14 @@ def conv_dgrad(gy, conv, spec, x_shape, weight_fn=None, tag="dgrad"):
 # weight gradient: MFMA kernel (wgrad_mfma.hip).  Thin gradients (the 1-channel PatchGAN logits)
 # are zero-padded to 8 channels so they take the same kernel.
 # ---------------------------------------------------------------------------------------------
-def conv_wgrad(x, gy, weight_shape, spec):
+# Gradient sinks (data-parallel runs): weight parameter -> its slice of the optimizer's flat all-reduce buffer.  A
+# convolution whose weight is registered here writes its weight gradient straight into that slice and returns it, so
+# autograd adopts a tensor that already lives in the buffer and no gather copy precedes the all-reduce.  Only sound for
+# a parameter that receives ONE contribution per backward pass (the caller's promise: vid2vid.FlatGrads(direct=True)).
+GRAD_SINKS = {}
+
+
+def conv_wgrad(x, gy, weight_shape, spec, out=None):
     cin, cout = x.shape[1], gy.shape[1]
     if cin % 8:
         raise NotImplementedError("weight gradient needs an input channel count that is a multiple of 8")
@@ -244,7 +251,7 @@ def conv_wgrad(x, gy, weight_shape, spec):
         return C.conv2d_wgrad(desc, x, gp)[:cout].contiguous()
     desc = C.make_desc(tuple(x.shape), cout, spec["k"], spec["stride"], spec["pad"], spec["pad_mode"], x.dtype,
                        bool(spec["transposed"]), spec.get("output_padding", 0))
-    return C.conv2d_wgrad(desc, x, gy)
+    return C.conv2d_wgrad(desc, x, gy, out=out)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -471,7 +478,8 @@ class ConvStageFn(Function):
                         return (g[:cin, :cout] if spec["transposed"] else g[:cout, :cin]).contiguous()
                     dw = wgrad_overlapped(conv, padded_wgrad, xin, gy)
                 else:
-                    dw = wgrad_overlapped(conv, lambda: conv_wgrad(xin, gy, tuple(conv.weight.shape), spec), xin, gy)
+                    sink = GRAD_SINKS.get(conv.weight) if GRAD_SINKS else None
+                    dw = wgrad_overlapped(conv, lambda: conv_wgrad(xin, gy, tuple(conv.weight.shape), spec, out=sink), xin, gy)
         r1 = gz if ctx.has_res[0] else None
         r2 = gz if ctx.has_res[1] else None
         if wfn is not None:      # reference-shaped parameter gradients

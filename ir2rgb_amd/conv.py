@@ -190,9 +190,10 @@ def conv2d_fwd(desc, x, wpacked, bias=None, want_stats=False, out=None):
     return y, stats
 
 
-def conv2d_wgrad(desc, x, gy):
+def conv2d_wgrad(desc, x, gy, out=None):
     """Weight gradient (fp32, torch weight layout) of the convolution ``desc`` from its forward input ``x`` and the
-    gradient ``gy`` w.r.t. its output (both channels_last half)."""
+    gradient ``gy`` w.r.t. its output (both channels_last half).  ``out``: a contiguous fp32 tensor of the weight's shape
+    to write into (e.g. a parameter's slice of a flat all-reduce buffer) instead of a fresh allocation."""
     if not (is_nhwc(x) and is_nhwc(gy)) or x.dtype != gy.dtype or _TORCH2DT.get(x.dtype) != desc.dtype:
         raise ValueError("conv2d_wgrad: x and gy must be channels_last half tensors of the descriptor's dtype")
     if tuple(x.shape) != (desc.N, desc.Cin, desc.Hin, desc.Win) or tuple(gy.shape) != (desc.N, desc.Cout, desc.Hout, desc.Wout):
@@ -203,7 +204,12 @@ def conv2d_wgrad(desc, x, gy):
         _lib.check(int(n), "conv2d_wgrad_workspace_elems")
     ws = torch.empty(n, dtype=torch.float32, device=x.device)
     shape = (desc.Cin, desc.Cout, desc.kh, desc.kw) if desc.transposed else (desc.Cout, desc.Cin, desc.kh, desc.kw)
-    dw = torch.empty(shape, dtype=torch.float32, device=x.device)
+    if out is not None:
+        if tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
+            raise ValueError("conv2d_wgrad: out must be a contiguous fp32 tensor of the weight's shape on the inputs' device")
+        dw = out
+    else:
+        dw = torch.empty(shape, dtype=torch.float32, device=x.device)
     with _lib.on_device(x):
         rc = lib.ir2rgb_conv2d_wgrad(ctypes.byref(desc), _p(x), _p(gy), _p(dw), _p(ws), _lib.current_stream(x))
     _lib.check(rc, "conv2d_wgrad")

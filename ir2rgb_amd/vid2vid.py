@@ -180,12 +180,18 @@ class FlowNet(torch.nn.Module):
 class FlatGrads:
     """One flat fp32 gradient buffer per optimizer.  ``zero`` drops the .grad references, so the first
     contribution of a backward pass is adopted by autograd without an add kernel per parameter;
-    ``all_reduce_async`` gathers the adopted tensors into the flat buffer with one multi-tensor copy
-    (world > 1 only), re-points .grad at the views and issues a chunked RCCL all-reduce (~128 MB per
-    collective).  A parameter that received no gradient gets a zero one, as the reference's
-    zero_grad() + Adam step would see (train_vid2vid.py:93-105)."""
+    ``all_reduce_async`` makes every .grad a view of the flat buffer and, for world > 1, issues a chunked
+    RCCL all-reduce (~128 MB per collective) that AVERAGES (ReduceOp.AVG: no scaling pass over the buffer).
+    A parameter that received no gradient gets a zero one, as the reference's zero_grad() + Adam step would
+    see (train_vid2vid.py:93-105).
 
-    def __init__(self, params, chunk_elems=32 * 1024 * 1024):
+    ``direct=True`` (world > 1, every parameter used once per backward pass -- the generators): the convolutions
+    write their weight gradients straight into their slices (ir2rgb_amd.autograd.GRAD_SINKS), so 99.9 % of the
+    buffer is in place when the pass ends; the rest (biases, BatchNorm parameters, first / thin / padded layers) is
+    gathered by one multi-tensor copy, as everything is when ``direct`` is off (the discriminators: several
+    contributions per parameter and pass, summed by the autograd engine before they are adopted)."""
+
+    def __init__(self, params, chunk_elems=32 * 1024 * 1024, world=1, direct=False):
         self.params = [p for p in params if p.requires_grad]
         pad4 = lambda k: (k + 3) & ~3  # noqa: E731  every view starts on a 16-byte boundary (vector path of adam_kernel)
         n = sum(pad4(p.numel()) for p in self.params)
@@ -197,6 +203,11 @@ class FlatGrads:
             off += pad4(p.numel())
         self.chunk = chunk_elems
         self.handles = []
+        self.scale_after = None
+        if direct and world > 1:
+            for p, v in zip(self.params, self.views):
+                if p.dim() == 4:
+                    autograd.GRAD_SINKS[p] = v
 
     def zero(self):
         for p in self.params:
@@ -208,23 +219,31 @@ class FlatGrads:
             if p.grad is None:
                 missing.append(v)
                 p.grad = v
-            elif world > 1:
+            elif world > 1 and p.grad.data_ptr() != v.data_ptr():
                 src.append(p.grad)
                 dst.append(v)
                 p.grad = v
+            elif world > 1:
+                p.grad = v              # written in place by its convolution (GRAD_SINKS)
         if missing:
             torch._foreach_zero_(missing)      # one multi-tensor launch instead of one fill per parameter
         if world <= 1:
             return
-        torch._foreach_copy_(dst, src)
-        self.flat.mul_(1.0 / world)
+        if src:
+            torch._foreach_copy_(dst, src)
+        avg = dist.get_backend() == "nccl"     # RCCL averages in the collective; gloo (CPU tests) has no AVG
+        self.scale_after = None if avg else 1.0 / world
         for i in range(0, self.flat.numel(), self.chunk):
-            self.handles.append(dist.all_reduce(self.flat[i:i + self.chunk], op=dist.ReduceOp.SUM, async_op=True))
+            self.handles.append(dist.all_reduce(self.flat[i:i + self.chunk], op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM,
+                                                async_op=True))
 
     def wait(self):
         for h in self.handles:
             h.wait()
         self.handles = []
+        if self.scale_after is not None:
+            self.flat.mul_(self.scale_after)
+            self.scale_after = None
 
 
 class Vid2VidTrainer:
@@ -268,7 +287,8 @@ class Vid2VidTrainer:
         # NOT fused=True: torch's fused Adam updates the parameters without bumping their version counters,
         # and the packed MFMA weights (ir2rgb_amd.layers.packed_weight) are refreshed on a version change
         adam = dict(lr=o["lr"], betas=(o["beta1"], 0.999), foreach=True)
-        self.grads_G = FlatGrads(g_params)
+        # (generators: one use per parameter and pass when one frame is generated per window, see generate())
+        self.grads_G = FlatGrads(g_params, world=world_size, direct=o["max_frames_per_gpu"] == 1)
         self.grads_D = FlatGrads(self.netD.parameters())
         self.grads_DT = [FlatGrads(d.parameters()) for d in self.netD_T]
         if o["fused_adam"]:
