@@ -213,7 +213,9 @@ def conv2d_wgrad(desc, x, gy, out=None):
     with _lib.on_device(x):
         rc = lib.ir2rgb_conv2d_wgrad(ctypes.byref(desc), _p(x), _p(gy), _p(dw), _p(ws), _lib.current_stream(x))
     _lib.check(rc, "conv2d_wgrad")
-    return dw
+    # (out: a NEW tensor object over the same memory -- autograd adopts a gradient without cloning it only when nobody
+    # else holds the object it is handed)
+    return dw if out is None else out.view(shape)
 
 
 def conv2d_fwd_view(desc, xbuf, wpacked, bias, ybuf, stats=None):
