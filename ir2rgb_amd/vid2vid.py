@@ -24,6 +24,7 @@ from . import autograd, layers, networks
 from .losses import fused_losses
 from .optim import FusedAdam
 from .ext import warp_diff_norm
+from .frames import FrameHistory
 
 DEFAULTS = dict(  # options/base_options.py, options/train_options.py
     input_nc=3, output_nc=3, n_input_gen_frames=3, first_layer_gen_filters=128, gen_network="composite", gen_ds_layers=3,
@@ -313,7 +314,11 @@ class Vid2VidTrainer:
     # ------------------------------------------------------------------ per-sequence state
     def reset_sequence(self):
         self.fake_B_prev = None          # pyramid of the last tG-1 generated frames
-        self.frames_all = [None] * 4     # real_B_all, fake_B_all, flow_ref_all, conf_ref_all
+        # histories of the four streams the temporal discriminators sub-sample (train_vid2vid.py:45-52: real_B_all,
+        # fake_B_all, flow_ref_all, conf_ref_all), each in one preallocated device buffer (ir2rgb_amd.frames)
+        ts, tD = self.t_scales, self.tD
+        self.hist = {"real": FrameHistory(ts, tD), "fake": FrameHistory(ts, tD), "flow": FrameHistory(1, tD),
+                     "conf": FrameHistory(1, tD)}
 
     # ------------------------------------------------------------------ generator (a8)
     def generate(self, real_A_all, real_B_all):
@@ -447,29 +452,15 @@ class Vid2VidTrainer:
         return {"D_T_real": d_real, "D_T_fake": d_fake, "G_T_GAN": g_gan, "G_T_GAN_Feat": g_fm}
 
     # ------------------------------------------------------------------ temporal frame bookkeeping
-    def _skipped(self, B_all, B, t_scales):
-        """get_skipped_frames (discriminator.py:257-271)."""
-        tD = self.tD
-        B_all = torch.cat([B_all.detach(), B], 1) if B_all is not None else B
-        skipped = [None] * t_scales
-        for s in range(t_scales):
-            step = tD ** s
-            span = step * (tD - 1)
-            n_groups = min(B_all.size(1) - span, B.size(1))
-            for t in range(0, max(n_groups, 0), tD):
-                sl = B_all[:, -span - t - 1:-t:step] if t else B_all[:, -span - 1::step]
-                skipped[s] = torch.cat([skipped[s], sl.contiguous()]) if skipped[s] is not None else sl.contiguous()
-        keep = tD ** (t_scales - 1) * (tD - 1)
-        return B_all[:, -keep:] if B_all.size(1) > keep else B_all, skipped
-
+    # get_skipped_frames (discriminator.py:257-271) lives in ir2rgb_amd.frames.FrameHistory.push: one preallocated
+    # device buffer per stream instead of a torch.cat of the whole history per window.
     def reference_flows(self, real_B, real_B_prev):
         """All FlowNet2 evaluations of one window in ONE batched call: the reference flow of the current
         frame (train_vid2vid.py:65) and the flows of the temporally skipped real triplets
         (discriminator.py:281-283).  Both depend on real frames only, so batching them changes nothing
         numerically (FlowNet2 is per-sample, frozen, eval mode)."""
         ts = self.t_scales
-        rb_all, rb_s = self._skipped(self.frames_all[0], real_B, ts)
-        self.frames_all[0] = rb_all
+        rb_s = self.hist["real"].push(real_B)
         firsts, seconds, owners = [real_B.reshape((-1,) + tuple(real_B.shape[2:]))], [real_B_prev.reshape((-1,) + tuple(real_B.shape[2:]))], []
         for s in range(1, ts):
             if rb_s[s] is not None and rb_s[s].size(1) == self.tD:
@@ -492,19 +483,14 @@ class Vid2VidTrainer:
         """get_all_skipped_frames, dense variant (discriminator.py:219-234, :273-283); the real-frame
         bookkeeping and the FlowNet2 calls were done by reference_flows."""
         ts = self.t_scales
-        _, fb_all, fl_all, cf_all = self.frames_all
-        fb_all, fb_s = self._skipped(fb_all, fake_B, ts)
-        fl_all, fl0 = self._skipped(fl_all, flow_ref, 1)
-        cf_all, cf0 = self._skipped(cf_all, conf_ref, 1)
+        fb_s = self.hist["fake"].push(fake_B)
+        fl0, cf0 = self.hist["flow"].push(flow_ref), self.hist["conf"].push(conf_ref)
         fl_s, cf_s = [None] * ts, [None] * ts
         if fl0[0] is not None:
             fl_s[0], cf_s[0] = fl0[0][:, 1:], cf0[0][:, 1:]
         for s in range(1, ts):
             if s in extra_flows:
                 fl_s[s], cf_s[s] = extra_flows[s]
-        # stored detached: the next window detaches the history anyway (discriminator.py:258), and a live reference
-        # would keep this window's generator graph (all saved activations) alive into the next one
-        self.frames_all[1:] = [fb_all.detach(), fl_all, cf_all]
         return rb_s, fb_s, fl_s, cf_s
 
     # ------------------------------------------------------------------ the loop body (a14)

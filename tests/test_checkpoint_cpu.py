@@ -7,7 +7,6 @@ import torch
 
 from ir2rgb_amd import checkpoint as CK
 from ir2rgb_amd import networks as N
-from ir2rgb_amd.data import VideoSeq
 
 OPT = dict(gen_blocks=2, n_blocks_local=1, fg=False, no_flow=False, n_local_enhancers=1, feat_num=3)
 
@@ -66,26 +65,3 @@ def test_iter_file_round_trip(tmp_path):
     assert CK.read_iter(str(tmp_path)) == (7, 123)
     e, i = np.loadtxt(tmp_path / "iter.txt", delimiter=",", dtype=int)  # what the reference's init_params does
     assert (int(e), int(i)) == (7, 123)
-
-
-@pytest.mark.parametrize("n_frames,tg,per_gpu,gpus", [(30, 3, 1, 1), (30, 3, 2, 2), (6, 3, 8, 1), (12, 2, 3, 1)])
-def test_video_seq_windows(n_frames, tg, per_gpu, gpus):
-    cin, cout, h, w = 3, 3, 4, 5
-    ir = torch.arange(n_frames * cin * h * w, dtype=torch.float32).view(1, n_frames * cin, h, w)
-    rgb = -torch.arange(n_frames * cout * h * w, dtype=torch.float32).view(1, n_frames * cout, h, w)
-    vs = VideoSeq(ir, rgb, None, n_input_gen_frames=tg, gen_gpus=gpus, input_nc=cin, output_nc=cout, max_frames_per_gpu=per_gpu)
-    want_load = min(per_gpu * gpus, n_frames - tg + 1)
-    want_t = want_load + per_gpu * gpus + tg - 1
-    assert (vs.n_frames_load, vs.t_len) == (want_load, want_t)
-    if n_frames - want_t + 1 < 0:
-        # the reference's __len__ returns a negative number for a video shorter than one window, which
-        # Python turns into ValueError: same here (mirrored behaviour, data/dataset/vid2vid.py:51-52)
-        with pytest.raises(ValueError):
-            len(vs)
-        return
-    assert len(vs) == (n_frames - want_t + 1) // want_t
-    if want_t <= n_frames:
-        a, b = vs[1]
-        assert a.shape == (1, want_t, cin, h, w) and b.shape == (1, want_t, cout, h, w)
-        # window i starts at frame i and holds t_len consecutive frames
-        assert torch.equal(a[0, 0], ir[0, cin:2 * cin]) and torch.equal(b[0, -1], rgb[0, want_t * cout:(want_t + 1) * cout])

@@ -260,7 +260,7 @@ def test_training_windows_vs_reference_golden(dev, golden_dir, case, dtype):
                   the generated-frame recurrence of a random-init generator is itself chaotic (a 1.7 % difference in the
                   frame fed back becomes 4 % in the next frame, 48 % in the one after; emulated and HIP run alike).
                   Windows 3-7 therefore restart from the REFERENCE's generated frames (trainer.fake_B_prev and the
-                  fake-frame history are overwritten from the golden file before each call): every window then checks
+                  fake-frame history (trainer.hist) are overwritten from the golden file before each call): every window then checks
                   the per-window computation and the temporal bookkeeping of both temporal scales (scale 1 needs 7
                   frames of history) at window-0 accuracy: loss terms 1e-2 / 3e-2, outputs 2 x floor + 0.01;
       ngf64       three windows with the three Adam steps each.  Adam's first step is lr * sign(gradient): every sign the
@@ -282,8 +282,7 @@ def test_training_windows_vs_reference_golden(dev, golden_dir, case, dtype):
         if forced and i >= n_floor:
             hist = [B[:, 0], B[:, 1]] + [torch.from_numpy(g[f"w{j}/fake_B"].astype(np.float32)).to(dev)[:, 0] for j in range(i)]
             tr.fake_B_prev = [torch.stack(hist[-(tG - 1):], 1)]
-            keep = tr.tD ** (tr.t_scales - 1) * (tr.tD - 1)
-            tr.frames_all[1] = torch.stack(hist[2:][-keep:], 1)
+            tr.hist["fake"].load(torch.stack(hist[2:], 1))
         out = tr.train_window(A[:, i:i + tG], B[:, i:i + tG])
         ref = {k.split("/")[-1]: float(g[k]) for k in g.files if k.startswith(f"w{i}/loss/")}
         got = {k: v.item() for k, v in out.items()}
