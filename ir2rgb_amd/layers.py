@@ -333,5 +333,8 @@ def bn_apply_add(a, b):
     if key not in _UNIT:
         _UNIT[key] = (torch.ones(ch, dtype=torch.float32, device=a.device),
                       torch.zeros(ch, dtype=torch.float32, device=a.device))
+        # shared by every later call on ANY stream (the generators run independent branches on two): the fills above
+        # were queued on the current stream only, so make them visible to all streams once
+        torch.cuda.synchronize(a.device)
     one, zero = _UNIT[key]
     return bn_apply(a, one, zero, ACT_NONE, res1=b)
