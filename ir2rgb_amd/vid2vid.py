@@ -117,18 +117,21 @@ class FlowNet(torch.nn.Module):
             p.requires_grad_(False)
 
     @torch.no_grad()
-    def forward(self, input_A, input_B):
+    def forward(self, input_A, input_B, side=None):
+        """``side``: a HIP stream a graph REPLAY of this call may run on (see Vid2VidTrainer.train_window); calls that
+        still have lazy work to do (eager warm-up, capture) stay on the current stream.  ``self.ran_on`` tells which."""
         if input_A.dim() == 5:
             b, n, c, h, w = input_A.shape
-            flow, conf = self.compute_flow_and_conf(input_A.reshape(-1, c, h, w), input_B.reshape(-1, c, h, w))
+            flow, conf = self.compute_flow_and_conf(input_A.reshape(-1, c, h, w), input_B.reshape(-1, c, h, w), side)
             return flow.view(b, n, 2, h, w), conf.view(b, n, 1, h, w)
-        return self.compute_flow_and_conf(input_A, input_B)
+        return self.compute_flow_and_conf(input_A, input_B, side)
 
-    def compute_flow_and_conf(self, im1, im2):
+    def compute_flow_and_conf(self, im1, im2, side=None):
         """FlowNet2 is frozen, runs without autograd and with fixed shapes: ~330 small launches per call.
         After two eager calls at a shape the whole call (convolutions, operators, interpolations, the
         confidence mask) is captured into a HIP graph and replayed -- one launch, no host work between
         the kernels.  Any failure to capture falls back to the eager path for that shape (logged once)."""
+        self.ran_on = None
         key = (tuple(im1.shape), im1.dtype, str(im1.device))
         ent = self._graphs.get(key)
         if not self.use_graph or not im1.is_cuda or ent is False:
@@ -151,6 +154,18 @@ class FlowNet(torch.nn.Module):
                       flush=True)
                 return self._flow_and_conf_eager(im1, im2)
         g, a, b, (flow, conf) = ent
+        if side is not None:
+            main = torch.cuda.current_stream(im1.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                a.copy_(im1)
+                b.copy_(im2)
+                g.replay()
+                out = flow.clone(), conf.clone()
+            for t in (im1, im2):
+                t.record_stream(side)
+            self.ran_on = side
+            return out
         a.copy_(im1)
         b.copy_(im2)
         g.replay()
@@ -307,6 +322,8 @@ class Vid2VidTrainer:
         import os
         if not t.is_cuda or os.environ.get("IR2RGB_FLOW_STREAM", "1") == "0":
             return None
+        if not isinstance(self.flow_net, FlowNet):
+            return None
         if getattr(self, "_flow_side", None) is None:
             self._flow_side = torch.cuda.Stream(t.device)
         return self._flow_side
@@ -454,7 +471,7 @@ class Vid2VidTrainer:
     # ------------------------------------------------------------------ temporal frame bookkeeping
     # get_skipped_frames (discriminator.py:257-271) lives in ir2rgb_amd.frames.FrameHistory.push: one preallocated
     # device buffer per stream instead of a torch.cat of the whole history per window.
-    def reference_flows(self, real_B, real_B_prev):
+    def reference_flows(self, real_B, real_B_prev, side=None):
         """All FlowNet2 evaluations of one window in ONE batched call: the reference flow of the current
         frame (train_vid2vid.py:65) and the flows of the temporally skipped real triplets
         (discriminator.py:281-283).  Both depend on real frames only, so batching them changes nothing
@@ -468,7 +485,10 @@ class Vid2VidTrainer:
                 firsts.append(a.reshape((-1,) + tuple(a.shape[2:])))
                 seconds.append(b.reshape((-1,) + tuple(b.shape[2:])))
                 owners.append((s, a.shape[0], a.shape[1]))
-        flow, conf = self.flow_net(torch.cat(firsts), torch.cat(seconds))
+        if side is not None and isinstance(self.flow_net, FlowNet):
+            flow, conf = self.flow_net(torch.cat(firsts), torch.cat(seconds), side=side)
+        else:
+            flow, conf = self.flow_net(torch.cat(firsts), torch.cat(seconds))
         n0 = firsts[0].shape[0]
         b, t = real_B.shape[:2]
         h, w = real_B.shape[-2:]
@@ -549,24 +569,21 @@ class Vid2VidTrainer:
         appended, ``G_T_GAN0`` ...).  ``self.last_outputs`` keeps (fake_B, fake_B_raw, flow, weight), detached."""
         fake_prev_last = self.fake_B_prev
         # The reference flows depend on real frames only (train_vid2vid.py:62-65 computes them after the generator, from
-        # real_Bp = input_B[:, tG-2:]): FlowNet2 -- a few hundred small launches, frozen, no autograd -- runs on a second
-        # HIP stream BESIDE the generator forward and is joined before the losses that read its result.
+        # real_Bp = input_B[:, tG-2:]): FlowNet2 -- frozen, no autograd, replayed from a HIP graph from its third call at a
+        # shape on -- runs on a second HIP stream BESIDE the generator forward and is joined before the losses that read
+        # its result (-1.0 ms per window).  Calls that are not yet replays (eager warm-up, capture: lazy work, see the
+        # hazard note in ir2rgb_amd/networks.py) run on the main stream, before the generator.
         tG = self.opt["n_input_gen_frames"]
         real_Bp_in = input_B[:, tG - 2:]
         side = self._flow_stream(input_B)
-        if side is not None:
-            main = torch.cuda.current_stream(input_B.device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                flow_ref, conf_ref, rb_s, extra_flows = self.reference_flows(real_Bp_in[:, 1:], real_Bp_in[:, :-1])
+        flow_ref, conf_ref, rb_s, extra_flows = self.reference_flows(real_Bp_in[:, 1:], real_Bp_in[:, :-1], side)
         fake_B, fake_B_raw, flow, weight, real_A, real_Bp = self.generate(input_A, input_B)
         real_B_prev, real_B = real_Bp[:, :-1], real_Bp[:, 1:]
-        if side is not None:
-            main.wait_stream(side)
-            for t in [flow_ref, conf_ref] + [x for pair in extra_flows.values() for x in pair] + [x for x in rb_s if x is not None]:
-                t.record_stream(main)
-        else:
-            flow_ref, conf_ref, rb_s, extra_flows = self.reference_flows(real_B, real_B_prev)
+        ran_on = getattr(self.flow_net, "ran_on", None)
+        if ran_on is not None:                      # FlowNet2 replayed on the side stream: join it here
+            torch.cuda.current_stream(input_B.device).wait_stream(ran_on)
+            for t in [flow_ref, conf_ref] + [x for pair in extra_flows.values() for x in pair]:
+                t.record_stream(torch.cuda.current_stream(input_B.device))
         # compute_fake_B_prev (generator.py:283-287) AS THE REFERENCE'S LOOP EVALUATES IT.  train_vid2vid.py:60,:67-68
         # hands the previous window's pyramid LIST to model_g and afterwards to compute_fake_B_prev; in between,
         # generate_frame_train appends the new frames to the elements of that very list (generator.py:113, :175:
