@@ -195,7 +195,7 @@ def main():
                 "kernel": kernel_name + " (MFMA implicit GEMM)",
                 "shape": dict(zip(("Cin", "Hin", "Win", "Cout", "kh", "kw", "stride", "reflect", "transposed"), dominant)),
                 "launches": n_launch, "avg_us": round(avg * 1e6, 1), "flops_per_launch": flops,
-                "note": "launches that overlap side-stream weight gradients are not bracketed (see DESIGN.md)"}
+                "note": "launches issued while FlowNet2 replays on the side stream (the generator forward) share the chip and are not bracketed (see DESIGN.md)"}
     all_conv_s = sum(v[0] for v in survey.values())
     all_conv_flops = sum(v[2] * v[1] for v in survey.values())
 
