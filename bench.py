@@ -196,12 +196,14 @@ def main():
                 "shape": dict(zip(("Cin", "Hin", "Win", "Cout", "kh", "kw", "stride", "reflect", "transposed"), dominant)),
                 "launches": n_launch, "avg_us": round(avg * 1e6, 1), "flops_per_launch": flops,
                 "note": "launches issued while FlowNet2 replays on the side stream (the generator forward) share the chip and are not bracketed (see DESIGN.md)"}
+    peak_mem = torch.cuda.max_memory_allocated(dev)
     all_conv_s = sum(v[0] for v in survey.values())
     all_conv_flops = sum(v[2] * v[1] for v in survey.values())
 
     # ---- generator-forward timings (north-star roofline config: single-scale composite ngf 128 @512x1024)
     extra = {"bracketed_conv_time_share_of_survey_window": round(all_conv_s / survey_s, 3),
-             "bracketed_conv_aggregate_TFLOPs": round(all_conv_flops / all_conv_s / 1e12, 1)}
+             "bracketed_conv_aggregate_TFLOPs": round(all_conv_flops / all_conv_s / 1e12, 1),
+             "max_memory_allocated_GB": round(peak_mem / 1e9, 2)}
     if rank == 0:
         from ir2rgb_amd import networks as N
         opt = dict(gen_blocks=9, n_blocks_local=3, fg=False, no_flow=False, n_local_enhancers=1, feat_num=3)

@@ -25,7 +25,11 @@ class FusedAdam:
         for p in self.params:
             if p.dtype != torch.float32 or not p.is_contiguous() or p.device != dev:
                 raise ValueError("FusedAdam: contiguous fp32 parameters on one device")
-        self.lr, self.betas, self.eps, self.step_count = lr, betas, eps, 0
+        # one parameter group, in torch.optim's shape: Model.update_learning_rate (base_model.py:103-108) walks
+        # ``optimizer.param_groups`` and assigns ``param_group['lr']``; the step reads lr / betas / eps from here
+        self.param_groups = [{"params": self.params, "lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": 0,
+                              "amsgrad": False}]
+        self.step_count = 0
         n = sum(p.numel() for p in self.params)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -47,6 +51,57 @@ class FusedAdam:
         self._blocks = torch.tensor(blocks, dtype=torch.int32, device=dev)
         self._ptrs = [p.data_ptr() for p in self.params]
         self.device = dev
+
+    @property
+    def lr(self):
+        return self.param_groups[0]["lr"]
+
+    @lr.setter
+    def lr(self, value):
+        self.param_groups[0]["lr"] = value
+
+    @property
+    def betas(self):
+        return self.param_groups[0]["betas"]
+
+    @property
+    def eps(self):
+        return self.param_groups[0]["eps"]
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    def state_dict(self):
+        """torch.optim.Adam's layout ({'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]}), so a
+        checkpoint written here loads into torch.optim.Adam over the same parameter list and vice versa."""
+        state = {}
+        if self.step_count:
+            for i in range(len(self.params)):
+                m, v = self.moments(i)
+                state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m.clone(), "exp_avg_sq": v.clone()}
+        g = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        g["params"] = list(range(len(self.params)))
+        return {"state": state, "param_groups": [g]}
+
+    def load_state_dict(self, sd):
+        g = sd["param_groups"][0]
+        if len(g["params"]) != len(self.params):
+            raise ValueError("FusedAdam.load_state_dict: parameter count differs")
+        self.param_groups[0].update({k: v for k, v in g.items() if k in ("lr", "betas", "eps")})
+        self.param_groups[0]["betas"] = tuple(self.param_groups[0]["betas"])
+        steps = {int(s["step"]) for s in sd["state"].values()}
+        if len(steps) > 1:
+            raise ValueError("FusedAdam.load_state_dict: parameters with different step counts (one launch updates all)")
+        self.step_count = steps.pop() if steps else 0
+        with torch.no_grad():
+            for i, s in sd["state"].items():
+                m, v = self.moments(int(i))
+                m.copy_(s["exp_avg"])
+                v.copy_(s["exp_avg_sq"])
 
     def moments(self, i):
         """(exp_avg, exp_avg_sq) views of parameter i (for tests / checkpoints)."""

@@ -98,6 +98,48 @@ def test_training_window_losses_fused_vs_torch_ops():
         assert abs(res[0][k] - res[1][k]) <= 2e-3 * abs(res[1][k]), (k, res[0][k], res[1][k])
 
 
+def test_fused_adam_param_groups_and_state_dict():
+    """The optimizer surface the reference touches: ``param_groups[...]['lr']`` (Model.update_learning_rate,
+    base_model.py:103-108), zero_grad, and a state_dict in torch.optim.Adam's layout -- a run can move between the two
+    optimizers in either direction and continue with the same updates."""
+    from ir2rgb_amd.optim import FusedAdam
+    dev = _dev()
+    g = torch.Generator().manual_seed(12)
+    init = [torch.randn(s, generator=g) for s in [(5,), (16, 3, 3, 3), (257,)]]
+    mine = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+    ref = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+    opt_m, opt_r = FusedAdam(mine, lr=2e-3, betas=(0.5, 0.999)), torch.optim.Adam(ref, lr=2e-3, betas=(0.5, 0.999))
+
+    def step(opts, lists):
+        grads = [torch.randn(p.shape, generator=g).to(dev) for p in lists[0]]
+        for lst in lists:
+            for p, gr in zip(lst, grads):
+                p.grad = gr.clone()
+        for o in opts:
+            o.step()
+
+    step([opt_m, opt_r], [mine, ref])
+    for o in (opt_m, opt_r):                       # the reference's learning-rate decay
+        for group in o.param_groups:
+            group["lr"] = 1e-3
+    step([opt_m, opt_r], [mine, ref])
+    assert all(torch.allclose(p, q, rtol=2e-6, atol=1e-7) for p, q in zip(mine, ref))
+    # FusedAdam -> torch.optim.Adam -> FusedAdam
+    mine2 = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    opt_t = torch.optim.Adam(mine2, lr=1.0, betas=(0.9, 0.9))
+    opt_t.load_state_dict(opt_m.state_dict())
+    assert opt_t.param_groups[0]["lr"] == 1e-3 and tuple(opt_t.param_groups[0]["betas"]) == (0.5, 0.999)
+    mine3 = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    opt_f = FusedAdam(mine3, lr=1.0, betas=(0.9, 0.9))
+    opt_f.load_state_dict(opt_t.state_dict())
+    assert opt_f.lr == 1e-3 and opt_f.step_count == 2
+    step([opt_m, opt_t, opt_f, opt_r], [mine, mine2, mine3, ref])
+    for a, b, c, d in zip(mine, mine2, mine3, ref):
+        assert torch.allclose(a, d, rtol=2e-6, atol=1e-7) and torch.allclose(b, d, rtol=2e-6, atol=1e-7) and torch.equal(a, c)
+    opt_m.zero_grad()
+    assert all(p.grad is None for p in mine)
+
+
 def test_fused_adam_matches_torch_adam():
     """ir2rgb_amd.optim.FusedAdam against torch.optim.Adam (the reference's optimizer) over 4 steps on
     tensors of awkward sizes, one of them with a gradient that is a 4-byte-aligned view (scalar path)."""
