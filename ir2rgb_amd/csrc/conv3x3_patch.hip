@@ -97,7 +97,7 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
                      uint16_t *__restrict__ Y, float *__restrict__ stats_partial, const P3Geom g) {
     typedef P3Cfg<TW, TCO, NCW, NLW, ADJ, SPS> C;
     static_assert(SPS == 1 || (PIPE && !ADJ), "two slices per step: pipelined forward form only");
-    static_assert(!(ADJ && PIPE), "reflect-adjoint terms read the patch after the tap they belong to: plain loop only");
+    static_assert(!(ADJ && PIPE) || C::NI <= 2, "pipelined reflect-adjoint form: border operands must be prefetched (small tile)");
     typedef P3Half<DT> Hf;
     typedef typename Hf::frag frag;
     constexpr int NI = C::NI, MI = 4;
@@ -338,6 +338,10 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
             int ks = 0;
             __builtin_amdgcn_s_barrier();                       // step 0 has landed
             fetch(0, wring, pbufs, 0, 0);
+            // reflect-adjoint mode: the border operands of a step are prefetched into registers as soon as the barrier
+            // that opens the step has passed (for step 0: here), and consumed right after the tap whose weights they
+            // use -- no LDS read of a step's data is left after the barrier that hands its weight stage back to the loaders
+            if constexpr (ADJ) prefetch_terms(pbufs, std::integral_constant<int, 0>{});
             // six steps per 64-channel chunk (two 32-channel slices x ky); the fragment buffers alternate with a
             // compile-time parity P (three taps per step flip it once per step)
             for (int cc = 0; cc < g.kchunks; ++cc) {
@@ -347,10 +351,13 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
                     const unsigned char *patch_next = pbufs + (HALF ^ 1) * C::PBUF;
                     const unsigned char *wst = wring + (ks % C::NSTW) * C::WST;
                     const unsigned char *wst_next = wring + ((ks + 1) % C::NSTW) * C::WST;
+                    using IKY = std::integral_constant<int, KY>;
                     fetch(P ^ 1, wst, patch, KY * C::PWP * 64, 1);
                     mma(P);                                      // tap kx = 0 (fetched during the previous step)
+                    if constexpr (ADJ) border_terms(patch, IKY{}, 0, P);
                     fetch(P, wst, patch, KY * C::PWP * 64, 2);
                     mma(P ^ 1);                                  // tap kx = 1
+                    if constexpr (ADJ) border_terms(patch, IKY{}, 1, P ^ 1);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read of step ks is complete
                     if (ks + 1 < NK) {
                         __builtin_amdgcn_s_barrier();            // step ks+1 has landed; stage ks may be overwritten
@@ -359,6 +366,13 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
                         else fetch(P ^ 1, wst_next, patch_next, 0, 0);
                     }
                     mma(P);                                      // tap kx = 2
+                    if constexpr (ADJ) {
+                        border_terms(patch, IKY{}, 2, P);
+                        if (ks + 1 < NK) {
+                            if constexpr (KY < 2) prefetch_terms(patch, std::integral_constant<int, KY + 1>{});
+                            else prefetch_terms(patch_next, std::integral_constant<int, 0>{});
+                        }
+                    }
                     ++ks;
                 };
                 using I0 = std::integral_constant<int, 0>;
@@ -555,8 +569,17 @@ int conv3x3p_launch(int variant, const P3Geom &g, int dtype, const void *x, cons
     } else {
         const unsigned grid = (unsigned)(npt * (g.Cout / 64));
         if (adj) {
-            if (dtype == IR2RGB_BF16) conv3x3_patch_kernel<IR2RGB_BF16, 64, 64, 4, 8, 0, 1, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
-            else conv3x3_patch_kernel<IR2RGB_F16, 64, 64, 4, 8, 0, 1, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+            // software-pipelined like the forward twin (border operands prefetched into registers); IR2RGB_CONV3X3P_ADJ_PIPE=0
+            // selects the plain loop (barrier at the top of every step) for A/B runs
+            static int adj_pipe = -1;
+            if (adj_pipe < 0) { const char *e = getenv("IR2RGB_CONV3X3P_ADJ_PIPE"); adj_pipe = e ? atoi(e) : 1; }
+            if (adj_pipe) {
+                if (dtype == IR2RGB_BF16) conv3x3_patch_kernel<IR2RGB_BF16, 64, 64, 4, 8, 1, 1, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+                else conv3x3_patch_kernel<IR2RGB_F16, 64, 64, 4, 8, 1, 1, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+            } else {
+                if (dtype == IR2RGB_BF16) conv3x3_patch_kernel<IR2RGB_BF16, 64, 64, 4, 8, 0, 1, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+                else conv3x3_patch_kernel<IR2RGB_F16, 64, 64, 4, 8, 0, 1, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+            }
         } else {
             if (p3_sps2()) {
                 if (dtype == IR2RGB_BF16) conv3x3_patch_kernel<IR2RGB_BF16, 64, 64, 4, 8, 1, 0, 2><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
