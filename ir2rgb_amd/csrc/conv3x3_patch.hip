@@ -563,6 +563,8 @@ int conv3x3p_launch(int variant, const P3Geom &g, int dtype, const void *x, cons
             if (dtype == IR2RGB_BF16) conv3x3_patch_kernel<IR2RGB_BF16, 128, 128, 8, 4, 0, 1, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
             else conv3x3_patch_kernel<IR2RGB_F16, 128, 128, 8, 4, 0, 1, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
         } else {
+            // (the pipelined form at this tile needs 2 x (MI + NI) fragment registers more than the 168 the 12-wave
+            // workgroup leaves a wave: measured in round 2, 8 VGPRs spilled -- the plain form stays)
             if (dtype == IR2RGB_BF16) conv3x3_patch_kernel<IR2RGB_BF16, 128, 128, 8, 4, 0, 0, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
             else conv3x3_patch_kernel<IR2RGB_F16, 128, 128, 8, 4, 0, 0, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
         }
