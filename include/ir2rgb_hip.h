@@ -200,6 +200,16 @@ int ir2rgb_bn_finalize_ex(const float *stats_partial, int rows, int C, long coun
                           float momentum, float eps, float *scale, float *shift, float *mean_out,
                           float *invstd_out, int stat_updates, int frozen, void *stream);
 
+/* ir2rgb_bn_finalize_ex (training mode, frozen = 0) and ir2rgb_bn_apply in ONE launch, for convolutions that wrote at
+ * most IR2RGB_BN_FUSED_MAX_ROWS partial rows (the residual blocks).  Same arithmetic in the same order: results are
+ * bit-identical to the two calls.  C % 64 == 0.  x / y / res1 / res2 as in ir2rgb_bn_apply (y may alias x). */
+#define IR2RGB_BN_FUSED_MAX_ROWS 128
+int ir2rgb_bn_finalize_apply(const float *stats_partial, int rows, int C, long count, const float *gamma,
+                             const float *beta, const float *conv_bias, float *running_mean, float *running_var,
+                             float momentum, float eps, float *scale, float *shift, float *mean_out,
+                             float *invstd_out, int stat_updates, const void *x, const void *res1, const void *res2,
+                             void *y, long npix, int act, int dtype, void *stream);
+
 /* y = act(x*scale[c] + shift[c]) + res1 + res2 on NHWC half tensors of npix pixels x C channels
  * (C % 8 == 0).  act: 0 none, 1 ReLU, 2 LeakyReLU(0.2).  res1/res2 may be NULL; y may alias x.
  * Covers norm+activation (networks.py:141-171, :253-271, :678-699), the ResnetBlock skip

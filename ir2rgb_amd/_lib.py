@@ -65,6 +65,8 @@ PROTOTYPES = {
     "ir2rgb_conv2d_kernel_name": (ctypes.c_char_p, [_pdesc]),
     "ir2rgb_bn_finalize": (c_int, [P, c_int, c_int, c_long, P, P, P, P, c_float, c_float, P, P, P, P, c_int, P]),
     "ir2rgb_bn_finalize_ex": (c_int, [P, c_int, c_int, c_long, P, P, P, P, P, c_float, c_float, P, P, P, P, c_int, c_int, P]),
+    "ir2rgb_bn_finalize_apply": (c_int, [P, c_int, c_int, c_long, P, P, P, P, P, c_float, c_float, P, P, P, P, c_int,
+                                         P, P, P, P, c_long, c_int, c_int, P]),
     "ir2rgb_bn_apply": (c_int, [P, P, P, P, P, P, c_long, c_int, c_int, c_int, P]),
     "ir2rgb_nchw_f32_to_nhwc_half": (c_int, [P, P] + [c_int] * 5 + [P]),
     "ir2rgb_nhwc_half_to_nchw_f32": (c_int, [P, P] + [c_int] * 5 + [P]),

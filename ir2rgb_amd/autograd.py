@@ -335,6 +335,7 @@ def wgrad_overlapped(conv, fn, *inputs):
 #                     discriminator's pass: nothing flows back into the generator)
 # ---------------------------------------------------------------------------------------------
 SKIP_PARAM_GRADS, SKIP_INPUT_GRAD = 1, 2
+FUSED_BN = os.environ.get("IR2RGB_FUSED_BN", "1") != "0"    # bn_finalize + bn_apply in one launch where the statistics are few rows
 
 
 @contextlib.contextmanager
@@ -396,10 +397,15 @@ class ConvStageFn(Function):
             ctx.frozen = L.bn_frozen(bn, spec["training"])
             y, stats = C.conv2d_fwd(desc, xin, wp, None, want_stats=not ctx.frozen)
             bnp = _PaddedBN(bn, cout_p) if cout_p != cout else bn
-            scale, shift, mean, invstd = L.bn_finalize(stats, desc.N * desc.Hout * desc.Wout, bnp, spec["training"], bias)
+            if FUSED_BN and not ctx.frozen and spec["training"] and stats.shape[0] <= L.FUSED_BN_MAX_ROWS and cout_p % 64 == 0:
+                # few partial rows (the residual blocks): statistics and apply in one launch
+                z, scale, shift, mean, invstd = L.bn_finalize_apply(stats, desc.N * desc.Hout * desc.Wout, bnp, y, spec["act"],
+                                                                    res1, res2, bias)
+            else:
+                scale, shift, mean, invstd = L.bn_finalize(stats, desc.N * desc.Hout * desc.Wout, bnp, spec["training"], bias)
+                z = L.bn_apply(y, scale, shift, spec["act"], res1, res2)
             if bnp is not bn:
                 bnp.commit(spec["training"])
-            z = L.bn_apply(y, scale, shift, spec["act"], res1, res2)
         else:
             y, _ = C.conv2d_fwd(desc, xin, wp, bias)
             z = y

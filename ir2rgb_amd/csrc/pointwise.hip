@@ -144,6 +144,116 @@ bn_apply_kernel(const uint4 *__restrict__ x, const float *__restrict__ scale, co
 }
 
 // ----------------------------------------------------------------------------------------
+// Statistics + apply in ONE launch, for layers whose convolution wrote few partial rows (the residual blocks: 8192
+// pixels = 32 rows).  bn_finalize -> bn_apply are two dependent launches of ~6 and ~16 us for a few MB: the first is
+// pure latency.  Here a block owns a 64-channel slice and a pixel range: it reduces the partial rows of ITS 64
+// channels itself (rows x 2 x 64 floats, <= 64 KB, L2-resident: every block of a slice reads the same lines), then
+// applies scale / shift / activation / residuals to its slice of the pixels (128-byte runs per pixel).  The sums run
+// in the same order and precision as bn_finalize_kernel (row order, double), so the result is bit-identical to the
+// two-launch path.  Block (slice, 0) also publishes scale / shift / mean / invstd (autograd saves them) and updates
+// the running statistics.  (Round 1 measured a variant in which every block reduced ALL channels: 27 us against
+// 12 + 10; with the slice it is the apply pass plus ~2 us.)
+// ----------------------------------------------------------------------------------------
+template <int DT>
+__global__ void __launch_bounds__(256)
+bn_finalize_apply_kernel(const float *__restrict__ partial, int rows, int C, double count, const float *__restrict__ gamma,
+                         const float *__restrict__ beta, const float *__restrict__ conv_bias, float *__restrict__ running_mean,
+                         float *__restrict__ running_var, float momentum, float eps, float *__restrict__ scale_out,
+                         float *__restrict__ shift_out, float *__restrict__ mean_out, float *__restrict__ invstd_out,
+                         int stat_updates, const uint4 *__restrict__ x, const uint4 *__restrict__ r1, const uint4 *__restrict__ r2,
+                         uint4 *__restrict__ y, long npix, int act, long pix_per_block) {
+    __shared__ double red[2][2][64];
+    __shared__ float ssc[64], ssh[64];
+    const int cg = blockIdx.x, c0 = cg * 64;
+    {
+        // 256 threads = (row half, which, channel): the two row halves are summed in row order, first half then second
+        const int cl = threadIdx.x & 63, which = (threadIdx.x >> 6) & 1, half = threadIdx.x >> 7;
+        const int h0 = half * ((rows + 1) / 2), h1 = half ? rows : (rows + 1) / 2;
+        double s = 0.0;
+        for (int r = h0; r < h1; r += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = partial[((long)min(r + u, rows - 1) * 2 + which) * C + c0 + cl];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += r + u < h1 ? (double)t[u] : 0.0;
+        }
+        red[half][which][cl] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int cl = threadIdx.x, c = c0 + cl;
+        const double s1 = red[0][0][cl] + red[1][0][cl], s2 = red[0][1][cl] + red[1][1][cl];
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        const float sc = g * invstd, sh = b - (float)mean * sc;
+        ssc[cl] = sc;
+        ssh[cl] = sh;
+        if (blockIdx.y == 0) {
+            scale_out[c] = sc;
+            shift_out[c] = sh;
+            if (mean_out) mean_out[c] = (float)mean;
+            if (invstd_out) invstd_out[c] = invstd;
+            if (running_mean) {
+                float r = running_mean[c];
+                const float m = (float)mean + (conv_bias ? conv_bias[c] : 0.f);
+                for (int u = 0; u < stat_updates; ++u) r = (1.f - momentum) * r + momentum * m;
+                running_mean[c] = r;
+            }
+            if (running_var) {
+                const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+                float r = running_var[c];
+                for (int u = 0; u < stat_updates; ++u) r = (1.f - momentum) * r + momentum * (float)unbiased;
+                running_var[c] = r;
+            }
+        }
+    }
+    __syncthreads();
+    // apply: lane = (pixel row within 32, channel octet of the slice); 16 bytes per lane, 128 bytes per pixel
+    const int oc = threadIdx.x & 7, prow = threadIdx.x >> 3;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = ssc[oc * 8 + j]; sh[j] = ssh[oc * 8 + j]; }
+    const int C8 = C >> 3;
+    const long p_begin = (long)blockIdx.y * pix_per_block, p_end = min(npix, p_begin + pix_per_block);
+    for (long p = p_begin + prow; p < p_end; p += 32 * 4) {
+        uint4 vx[4], va[4], vb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long q = min(p + 32 * u, p_end - 1), i = q * C8 + cg * 8 + oc;      // clamped: masked at the store
+            vx[u] = x[i];
+            va[u] = r1 ? r1[i] : make_uint4(0, 0, 0, 0);
+            vb[u] = r2 ? r2[i] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long q = p + 32 * u;
+            if (q >= p_end) break;
+            const uint32_t w[4] = {vx[u].x, vx[u].y, vx[u].z, vx[u].w}, a[4] = {va[u].x, va[u].y, va[u].z, va[u].w},
+                           b[4] = {vb[u].x, vb[u].y, vb[u].z, vb[u].w};
+            uint32_t o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float f[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float t = h2f((uint16_t)(w[j] >> (16 * h)), DT) * sc[2 * j + h] + sh[2 * j + h];
+                    if (act == 1) t = t > 0.f ? t : 0.f;
+                    else if (act == 2) t = t > 0.f ? t : 0.2f * t;
+                    if (r1) t += h2f((uint16_t)(a[j] >> (16 * h)), DT);
+                    if (r2) t += h2f((uint16_t)(b[j] >> (16 * h)), DT);
+                    f[h] = t;
+                }
+                o[j] = (uint32_t)f2h(f[0], DT) | ((uint32_t)f2h(f[1], DT) << 16);
+            }
+            y[q * C8 + cg * 8 + oc] = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------
 // layout converters (LDS-tiled transposes: coalesced on both sides)
 //   NCHW fp32 [N][C][HW]  <->  NHWC half [N][HW][C]
 // tile = 64 pixels x 64 channels per workgroup of 256 threads.
@@ -302,6 +412,35 @@ extern "C" int ir2rgb_bn_finalize_ex(const float *stats_partial, int rows, int C
     bn_finalize_kernel<<<cdiv(C, 32), 1024, 0, as_stream(stream)>>>(stats_partial, rows, C, (double)count, gamma, beta,
                                                                     conv_bias, running_mean, running_var, momentum, eps,
                                                                     scale, shift, mean_out, invstd_out, stat_updates);
+    return ir2rgb_launch_status();
+}
+
+extern "C" int ir2rgb_bn_finalize_apply(const float *stats_partial, int rows, int C, long count, const float *gamma,
+                                        const float *beta, const float *conv_bias, float *running_mean,
+                                        float *running_var, float momentum, float eps, float *scale, float *shift,
+                                        float *mean_out, float *invstd_out, int stat_updates, const void *x,
+                                        const void *res1, const void *res2, void *y, long npix, int act, int dtype,
+                                        void *stream) {
+    if (rows < 1 || rows > IR2RGB_BN_FUSED_MAX_ROWS || C < 64 || (C % 64) || count < 1 || npix < 1 || !stats_partial ||
+        !scale || !shift || !x || !y || stat_updates < 1 || act < 0 || act > 2)
+        return IR2RGB_EINVAL;
+    if (dtype != IR2RGB_BF16 && dtype != IR2RGB_F16) return IR2RGB_ENOSUP;
+    if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)res1 | (uintptr_t)res2) & 15)) return IR2RGB_EALIGN;
+    // about 2048 blocks in all, at least 128 pixels each
+    long chunks = 2048 / (C / 64);
+    const long cap = (npix + 127) / 128;
+    chunks = chunks < 1 ? 1 : (chunks > cap ? cap : chunks);
+    const long per = (npix + chunks - 1) / chunks;
+    dim3 grid((unsigned)(C / 64), (unsigned)((npix + per - 1) / per));
+    hipStream_t s = as_stream(stream);
+    if (dtype == IR2RGB_BF16)
+        bn_finalize_apply_kernel<IR2RGB_BF16><<<grid, 256, 0, s>>>(stats_partial, rows, C, (double)count, gamma, beta, conv_bias,
+            running_mean, running_var, momentum, eps, scale, shift, mean_out, invstd_out, stat_updates, (const uint4 *)x,
+            (const uint4 *)res1, (const uint4 *)res2, (uint4 *)y, npix, act, per);
+    else
+        bn_finalize_apply_kernel<IR2RGB_F16><<<grid, 256, 0, s>>>(stats_partial, rows, C, (double)count, gamma, beta, conv_bias,
+            running_mean, running_var, momentum, eps, scale, shift, mean_out, invstd_out, stat_updates, (const uint4 *)x,
+            (const uint4 *)res1, (const uint4 *)res2, (uint4 *)y, npix, act, per);
     return ir2rgb_launch_status();
 }
 

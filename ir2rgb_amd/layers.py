@@ -146,6 +146,32 @@ def bn_finalize(stats, count, bn, training=True, conv_bias=None):
     return scale, shift, mean, invstd
 
 
+FUSED_BN_MAX_ROWS = 128      # IR2RGB_BN_FUSED_MAX_ROWS of include/ir2rgb_hip.h
+
+
+def bn_finalize_apply(stats, count, bn, y, act, res1=None, res2=None, conv_bias=None):
+    """Training-mode ``bn_finalize`` + ``bn_apply`` as one launch (ir2rgb_bn_finalize_apply) for convolutions with few
+    partial rows.  -> (z, scale, shift, mean, invstd), bit-identical to the two calls."""
+    rows, _, ch = stats.shape
+    n, _, h, w = y.shape
+    dev = y.device
+    scale = torch.empty(ch, dtype=torch.float32, device=dev)
+    shift, mean, invstd = torch.empty_like(scale), torch.empty_like(scale), torch.empty_like(scale)
+    z = torch.empty_like(y, memory_format=torch.channels_last)
+    track = bn.track_running_stats and bn.running_mean is not None
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    with _lib.on_device(y):
+        rc = _lib.lib().ir2rgb_bn_finalize_apply(_p(stats), rows, ch, int(count), _p(bn.weight), _p(bn.bias), _p(conv_bias),
+                                                 _p(bn.running_mean) if track else _p(None),
+                                                 _p(bn.running_var) if track else _p(None), float(momentum), float(bn.eps),
+                                                 _p(scale), _p(shift), _p(mean), _p(invstd), _STAT_UPDATES, _p(y), _p(res1),
+                                                 _p(res2), _p(z), n * h * w, act, _DT[y.dtype], _lib.current_stream(y))
+    _lib.check(rc, "bn_finalize_apply")
+    if track and bn.num_batches_tracked is not None:
+        _PENDING_COUNTERS.append((bn.num_batches_tracked, _STAT_UPDATES))
+    return z, scale, shift, mean, invstd
+
+
 _PENDING_COUNTERS = []
 
 

@@ -292,3 +292,37 @@ def test_branch_streams_are_bit_exact(dev, model):
         torch.cuda.synchronize()
         assert all(torch.equal(a, b) for a, b in zip(one, two)), f"call {it}"
     assert N.BRANCH_STREAMS == "0"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(1, 256, 32, 64, 256), (2, 128, 9, 13, 192), (1, 1024, 16, 32, 1024)])
+def test_fused_bn_finalize_apply_is_bit_identical(dev, dtype, shape):
+    """ir2rgb_bn_finalize_apply (statistics + scale/shift/ReLU/residuals in one launch, used where the convolution wrote
+    few partial rows) against ir2rgb_bn_finalize_ex + ir2rgb_bn_apply: outputs, saved statistics and running
+    statistics bit for bit."""
+    import copy
+    from ir2rgb_amd import autograd as A
+    from ir2rgb_amd import conv as C
+    from ir2rgb_amd import layers as L
+    n, cin, h, w, cout = shape
+    gen = torch.Generator().manual_seed(cin + h)
+    x = torch.randn(n, cin, h, w, generator=gen).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    res = torch.randn(n, cout, h, w, generator=gen).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=0).to(dev)
+    bn = torch.nn.BatchNorm2d(cout).to(dev)
+    with torch.no_grad():
+        bn.weight.normal_(1.0, 0.2)
+        bn.bias.normal_(0.0, 0.2)
+    outs = []
+    for fused in (True, False):
+        A.FUSED_BN = fused
+        c2, b2 = copy.deepcopy(conv), copy.deepcopy(bn)
+        try:
+            with torch.no_grad(), L.repeated_forward(2):
+                z = A.conv_stage(x, c2, b2, L.ACT_RELU, C.PAD_REFLECT, dtype, pad=1, res1=res, training=True)
+        finally:
+            A.FUSED_BN = True
+        outs.append((z, b2.running_mean.clone(), b2.running_var.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert torch.isfinite(outs[0][0].float()).all()
