@@ -295,7 +295,7 @@ def test_branch_streams_are_bit_exact(dev, model):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("shape", [(1, 256, 32, 64, 256), (2, 128, 9, 13, 192), (1, 1024, 16, 32, 1024)])
+@pytest.mark.parametrize("shape", [(1, 256, 32, 64, 256), (2, 128, 9, 13, 128), (1, 1024, 16, 32, 1024)])
 def test_fused_bn_finalize_apply_is_bit_identical(dev, dtype, shape):
     """ir2rgb_bn_finalize_apply (statistics + scale/shift/ReLU/residuals in one launch, used where the convolution wrote
     few partial rows) against ir2rgb_bn_finalize_ex + ir2rgb_bn_apply: outputs, saved statistics and running
