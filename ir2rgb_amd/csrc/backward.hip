@@ -193,6 +193,80 @@ bn_bwd_apply_kernel(const uint4 *__restrict__ gz, const uint4 *__restrict__ y, c
     }
 }
 
+// bn_bwd_finalize + bn_bwd_apply in one launch (BatchNorm stages): a block owns a 64-channel slice and a pixel range;
+// it sums the R <= 128 partial rows of ITS 64 channels (same order and precision as bn_bwd_finalize_kernel: slices of
+// 8 rows apart, then the 8 slices, in double), derives the three coefficients, and applies them to its pixels.
+// Block (slice, 0) publishes dgamma / dbeta.  One dependent launch (~5 us of pure latency) less per BatchNorm layer
+// and backward pass: 150 of them per training window.
+__global__ void __launch_bounds__(256)
+bn_bwd_finalize_apply_kernel(const float *__restrict__ partial, int R, int C, const float *__restrict__ scale,
+                             const float *__restrict__ shift, const float *__restrict__ mean, const float *__restrict__ invstd,
+                             float inv_n, float *__restrict__ dgamma, float *__restrict__ dbeta, const uint4 *__restrict__ gz,
+                             const uint4 *__restrict__ y, uint4 *__restrict__ gy, long npix, int act, int dt, long pix_per_block) {
+    __shared__ double fin[2][2][64];
+    __shared__ float co[3][64], ssc[64], ssh[64];
+    const int cg = blockIdx.x, c0 = cg * 64;
+    {
+        // 256 threads = (group of slices, which, channel): group h sums the slices k = 4h .. 4h+3 of bn_bwd_finalize_kernel's
+        // order (slice k = rows k, k+8, k+16, ...), so that (group 0) + (group 1) = its slice-ordered total
+        const int cl = threadIdx.x & 63, which = (threadIdx.x >> 6) & 1, h = threadIdx.x >> 7;
+        double a = 0.0;
+        for (int k = 4 * h; k < 4 * h + 4; ++k) {
+            float t[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t[u] = partial[((long)min(k + 8 * u, R - 1) * 2 + which) * C + c0 + cl];
+            double sl = 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) sl += k + 8 * u < R ? (double)t[u] : 0.0;
+            a += sl;
+        }
+        fin[h][which][cl] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int cl = threadIdx.x, c = c0 + cl;
+        const double a = fin[0][0][cl] + fin[1][0][cl], b = fin[0][1][cl] + fin[1][1][cl];
+        const float scv = scale[c], isv = invstd[c], muv = mean[c];
+        const float dg = (float)b * inv_n, db = (float)a * inv_n;
+        co[0][cl] = scv;
+        co[1][cl] = -scv * isv * dg;
+        co[2][cl] = scv * (isv * muv * dg - db);
+        ssc[cl] = scv;
+        ssh[cl] = shift[c];
+        if (blockIdx.y == 0) { dbeta[c] = (float)a; dgamma[c] = (float)b; }
+    }
+    __syncthreads();
+    const int oc = threadIdx.x & 7, prow = threadIdx.x >> 3;
+    float sc[8], sh[8], cA[8], cB[8], cC[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sc[j] = ssc[oc * 8 + j]; sh[j] = ssh[oc * 8 + j];
+        cA[j] = co[0][oc * 8 + j]; cB[j] = co[1][oc * 8 + j]; cC[j] = co[2][oc * 8 + j];
+    }
+    const int C8 = C >> 3;
+    const long p_begin = (long)blockIdx.y * pix_per_block, p_end = min(npix, p_begin + pix_per_block);
+    for (long p = p_begin + prow; p < p_end; p += 32 * 4) {
+        uint4 gq[4], yq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long q = min(p + 32 * u, p_end - 1), i = q * C8 + cg * 8 + oc;
+            gq[u] = gz[i];
+            yq[u] = y[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long q = p + 32 * u;
+            if (q >= p_end) break;
+            float g[8], v[8], o[8];
+            unpack8(gq[u], g, dt);
+            unpack8(yq[u], v, dt);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = cA[j] * act_grad(g[j], v[j] * sc[j] + sh[j], act) + cB[j] * v[j] + cC[j];
+            gy[q * C8 + cg * 8 + oc] = pack8(o, dt);
+        }
+    }
+}
+
 // dx[n][y][x][c] = sum over padded positions (py,px) that reflect onto (y,x) of dxpad[n][py][px][c]
 __global__ void __launch_bounds__(256)
 fold_reflect_kernel(const uint4 *__restrict__ dxpad, uint4 *__restrict__ dx, int H, int W, int C8, int pady, int padx,
@@ -338,6 +412,19 @@ extern "C" int ir2rgb_bn_bwd(const void *gz, const void *y, const float *scale, 
     float *coef = partial + (long)R * 2 * C;
     bn_bwd_reduce_kernel<<<R * (C / 64), 512, 0, s>>>((const uint4 *)gz, (const uint4 *)y, scale, shift, mean, invstd,
                                                       partial, npix, C, act, dtype, per);
+    static int fused = -1;
+    if (fused < 0) { const char *e = getenv("IR2RGB_FUSED_BN_BWD"); fused = e ? atoi(e) : 1; }
+    if (fused && scale && shift && mean && invstd) {
+        long chunks = 2048 / (C / 64);
+        const long cap = (npix + 127) / 128;
+        chunks = chunks < 1 ? 1 : (chunks > cap ? cap : chunks);
+        const long pp = (npix + chunks - 1) / chunks;
+        dim3 grid((unsigned)(C / 64), (unsigned)((npix + pp - 1) / pp));
+        bn_bwd_finalize_apply_kernel<<<grid, 256, 0, s>>>(partial, R, C, scale, shift, mean, invstd,
+                                                          frozen ? 0.f : 1.0f / (float)npix, dgamma, dbeta, (const uint4 *)gz,
+                                                          (const uint4 *)y, (uint4 *)gy, npix, act, dtype, pp);
+        return ir2rgb_launch_status();
+    }
     bn_bwd_finalize_kernel<<<C / 64, 1024, 0, s>>>(partial, R, C, scale, mean, invstd, frozen ? 0.f : 1.0f / (float)npix, dgamma, dbeta,
                                                   coef);
     long total8 = npix * (C / 8);
