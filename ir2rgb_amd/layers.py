@@ -113,6 +113,20 @@ def repeated_forward(times):
         _STAT_UPDATES = old
 
 
+def _bn_ptrs(bn):
+    """ctypes pointers of a BatchNorm module's tensors, cached on the module (nn.Module attribute look-ups and ctypes
+    conversions cost ~10 us per call, twice per stage and pass); rebuilt when the weight's storage moves."""
+    hit = bn.__dict__.get("_ir2rgb_ptrs")
+    w = bn.weight
+    if hit is not None and hit[0] == (w.data_ptr() if w is not None else 0):
+        return hit
+    rm, rv = bn.running_mean, bn.running_var
+    hit = (w.data_ptr() if w is not None else 0, _p(w), _p(bn.bias), _p(rm), _p(rv), rm is not None,
+           0.1 if bn.momentum is None else float(bn.momentum), float(bn.eps), bool(bn.track_running_stats))
+    bn.__dict__["_ir2rgb_ptrs"] = hit
+    return hit
+
+
 def bn_frozen(bn, training):
     """True when nn.BatchNorm2d would normalise with its running statistics (module.eval() and tracked stats)."""
     return (not training) and bn.track_running_stats and bn.running_mean is not None
@@ -154,18 +168,24 @@ def bn_finalize_apply(stats, count, bn, y, act, res1=None, res2=None, conv_bias=
     partial rows.  -> (z, scale, shift, mean, invstd), bit-identical to the two calls."""
     rows, _, ch = stats.shape
     n, _, h, w = y.shape
-    dev = y.device
-    scale = torch.empty(ch, dtype=torch.float32, device=dev)
-    shift, mean, invstd = torch.empty_like(scale), torch.empty_like(scale), torch.empty_like(scale)
+    vec = torch.empty((4, ch), dtype=torch.float32, device=y.device)       # scale | shift | mean | invstd: one allocation
+    scale, shift, mean, invstd = vec[0], vec[1], vec[2], vec[3]
     z = torch.empty_like(y, memory_format=torch.channels_last)
-    track = bn.track_running_stats and bn.running_mean is not None
-    momentum = 0.1 if bn.momentum is None else bn.momentum
+    if isinstance(bn, nn.Module):
+        _, pw, pb, prm, prv, has_rm, momentum, eps, trs = _bn_ptrs(bn)
+    else:       # a padded shadow (autograd._PaddedBN): fresh tensors every call
+        pw, pb, prm, prv, has_rm = _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var), bn.running_mean is not None
+        momentum, eps, trs = 0.1 if bn.momentum is None else float(bn.momentum), float(bn.eps), bn.track_running_stats
+    track = trs and has_rm
+    base = vec.data_ptr()
+    null = ctypes.c_void_p(0)
     with _lib.on_device(y):
-        rc = _lib.lib().ir2rgb_bn_finalize_apply(_p(stats), rows, ch, int(count), _p(bn.weight), _p(bn.bias), _p(conv_bias),
-                                                 _p(bn.running_mean) if track else _p(None),
-                                                 _p(bn.running_var) if track else _p(None), float(momentum), float(bn.eps),
-                                                 _p(scale), _p(shift), _p(mean), _p(invstd), _STAT_UPDATES, _p(y), _p(res1),
-                                                 _p(res2), _p(z), n * h * w, act, _DT[y.dtype], _lib.current_stream(y))
+        rc = _lib.lib().ir2rgb_bn_finalize_apply(_p(stats), rows, ch, int(count), pw, pb, _p(conv_bias),
+                                                 prm if track else null, prv if track else null, momentum, eps,
+                                                 ctypes.c_void_p(base), ctypes.c_void_p(base + 4 * ch),
+                                                 ctypes.c_void_p(base + 8 * ch), ctypes.c_void_p(base + 12 * ch),
+                                                 _STAT_UPDATES, _p(y), _p(res1), _p(res2), _p(z), n * h * w, act,
+                                                 _DT[y.dtype], _lib.current_stream(y))
     _lib.check(rc, "bn_finalize_apply")
     if track and bn.num_batches_tracked is not None:
         _PENDING_COUNTERS.append((bn.num_batches_tracked, _STAT_UPDATES))
