@@ -307,6 +307,13 @@ long ir2rgb_conv2d_wgrad_workspace_elems(const ir2rgb_conv_desc *d);
 int ir2rgb_conv2d_wgrad(const ir2rgb_conv_desc *d, const void *x, const void *gy, float *dw, float *workspace,
                         void *stream);
 
+/* dw += the same weight gradient (a parameter that is used several times in one backward pass: the discriminators are
+ * applied to two or three inputs per window, discriminator.py:154-166): the sum with the earlier contributions happens in
+ * the kernel's own finish pass instead of in a separate add.  Workspace: ir2rgb_conv2d_wgrad_acc_workspace_elems. */
+int ir2rgb_conv2d_wgrad_acc(const ir2rgb_conv_desc *d, const void *x, const void *gy, float *dw, float *workspace,
+                            void *stream);
+long ir2rgb_conv2d_wgrad_acc_workspace_elems(const ir2rgb_conv_desc *d);
+
 /* FlowNet2 flow up-sampler ConvTranspose2d(2,2,4,2,1) (reference FlowNetC.py:47-50 etc.): in [N,2,h,w]
  * fp32 NCHW, weight [2,2,4,4], bias [2] or NULL -> channels [c_off, c_off+2) of an NHWC half buffer
  * [N,2h,2w,ld]. */

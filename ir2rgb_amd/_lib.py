@@ -84,7 +84,9 @@ PROTOTYPES = {
     "ir2rgb_warp_blend_bwd": (c_int, [P] * 8 + [c_int] * 4 + [P]),
     "ir2rgb_xexpand_bwd": (c_int, [P, P] + [c_int] * 10 + [P]),
     "ir2rgb_conv2d_wgrad_workspace_elems": (c_long, [_pdesc]),
+    "ir2rgb_conv2d_wgrad_acc_workspace_elems": (c_long, [_pdesc]),
     "ir2rgb_conv2d_wgrad": (c_int, [_pdesc, P, P, P, P, P]),
+    "ir2rgb_conv2d_wgrad_acc": (c_int, [_pdesc, P, P, P, P, P]),
     "ir2rgb_loss_partial_elems": (c_int, []),
     "ir2rgb_loss_multi_fwd": (c_int, [_pitem, c_int, c_int, P, P, P]),
     "ir2rgb_loss_multi_bwd": (c_int, [_pitem, c_int, c_int, P, P]),

@@ -236,7 +236,7 @@ def conv_dgrad(gy, conv, spec, x_shape, weight_fn=None, tag="dgrad"):
 GRAD_SINKS = {}
 
 
-def conv_wgrad(x, gy, weight_shape, spec, out=None):
+def conv_wgrad(x, gy, weight_shape, spec, out=None, accumulate=False):
     cin, cout = x.shape[1], gy.shape[1]
     if cin % 8:
         raise NotImplementedError("weight gradient needs an input channel count that is a multiple of 8")
@@ -251,7 +251,7 @@ def conv_wgrad(x, gy, weight_shape, spec, out=None):
         return C.conv2d_wgrad(desc, x, gp)[:cout].contiguous()
     desc = C.make_desc(tuple(x.shape), cout, spec["k"], spec["stride"], spec["pad"], spec["pad_mode"], x.dtype,
                        bool(spec["transposed"]), spec.get("output_padding", 0))
-    return C.conv2d_wgrad(desc, x, gy, out=out)
+    return C.conv2d_wgrad(desc, x, gy, out=out, accumulate=accumulate)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -335,6 +335,7 @@ def wgrad_overlapped(conv, fn, *inputs):
 #                     discriminator's pass: nothing flows back into the generator)
 # ---------------------------------------------------------------------------------------------
 SKIP_PARAM_GRADS, SKIP_INPUT_GRAD = 1, 2
+ACCUMULATE_IN_KERNEL = os.environ.get("IR2RGB_WGRAD_ACC", "1") != "0"    # dw += inside the weight-gradient kernel (see backward)
 FUSED_BN = os.environ.get("IR2RGB_FUSED_BN", "1") != "0"    # bn_finalize + bn_apply in one launch where the statistics are few rows
 
 
@@ -485,7 +486,14 @@ class ConvStageFn(Function):
                     dw = wgrad_overlapped(conv, padded_wgrad, xin, gy)
                 else:
                     sink = GRAD_SINKS.get(conv.weight) if GRAD_SINKS else None
-                    dw = wgrad_overlapped(conv, lambda: conv_wgrad(xin, gy, tuple(conv.weight.shape), spec, out=sink), xin, gy)
+                    have = conv.weight.grad
+                    if (ACCUMULATE_IN_KERNEL and sink is None and have is not None and have.dtype == torch.float32
+                            and have.is_contiguous() and have.shape == conv.weight.shape):
+                        # a later use of the same parameter in this pass (the discriminators see two or three inputs per
+                        # window): dw is added to .grad by the kernel's own finish pass; autograd gets nothing to add
+                        conv_wgrad(xin, gy, tuple(conv.weight.shape), spec, out=have, accumulate=True)
+                    else:
+                        dw = wgrad_overlapped(conv, lambda: conv_wgrad(xin, gy, tuple(conv.weight.shape), spec, out=sink), xin, gy)
         r1 = gz if ctx.has_res[0] else None
         r2 = gz if ctx.has_res[1] else None
         if wfn is not None:      # reference-shaped parameter gradients

@@ -190,16 +190,19 @@ def conv2d_fwd(desc, x, wpacked, bias=None, want_stats=False, out=None):
     return y, stats
 
 
-def conv2d_wgrad(desc, x, gy, out=None):
+def conv2d_wgrad(desc, x, gy, out=None, accumulate=False):
     """Weight gradient (fp32, torch weight layout) of the convolution ``desc`` from its forward input ``x`` and the
     gradient ``gy`` w.r.t. its output (both channels_last half).  ``out``: a contiguous fp32 tensor of the weight's shape
-    to write into (e.g. a parameter's slice of a flat all-reduce buffer) instead of a fresh allocation."""
+    to write into (e.g. a parameter's slice of a flat all-reduce buffer) instead of a fresh allocation.
+    ``accumulate`` (with ``out``): out += the gradient, summed in the kernel's finish pass (ir2rgb_conv2d_wgrad_acc)."""
     if not (is_nhwc(x) and is_nhwc(gy)) or x.dtype != gy.dtype or _TORCH2DT.get(x.dtype) != desc.dtype:
         raise ValueError("conv2d_wgrad: x and gy must be channels_last half tensors of the descriptor's dtype")
     if tuple(x.shape) != (desc.N, desc.Cin, desc.Hin, desc.Win) or tuple(gy.shape) != (desc.N, desc.Cout, desc.Hout, desc.Wout):
         raise ValueError("conv2d_wgrad: shapes do not match the descriptor")
     lib = _lib.lib()
-    n = lib.ir2rgb_conv2d_wgrad_workspace_elems(ctypes.byref(desc))
+    if accumulate and out is None:
+        raise ValueError("conv2d_wgrad: accumulate needs the tensor to add to (out)")
+    n = (lib.ir2rgb_conv2d_wgrad_acc_workspace_elems if accumulate else lib.ir2rgb_conv2d_wgrad_workspace_elems)(ctypes.byref(desc))
     if n < 0:
         _lib.check(int(n), "conv2d_wgrad_workspace_elems")
     ws = torch.empty(n, dtype=torch.float32, device=x.device)
@@ -211,8 +214,11 @@ def conv2d_wgrad(desc, x, gy, out=None):
     else:
         dw = torch.empty(shape, dtype=torch.float32, device=x.device)
     with _lib.on_device(x):
-        rc = lib.ir2rgb_conv2d_wgrad(ctypes.byref(desc), _p(x), _p(gy), _p(dw), _p(ws), _lib.current_stream(x))
+        fn = lib.ir2rgb_conv2d_wgrad_acc if accumulate else lib.ir2rgb_conv2d_wgrad
+        rc = fn(ctypes.byref(desc), _p(x), _p(gy), _p(dw), _p(ws), _lib.current_stream(x))
     _lib.check(rc, "conv2d_wgrad")
+    if accumulate:
+        return None
     # (out: a NEW tensor object over the same memory -- autograd adopts a gradient without cloning it only when nobody
     # else holds the object it is handed)
     return dw if out is None else out.view(shape)

@@ -536,7 +536,7 @@ static bool plan9(const ir2rgb_conv_desc *d, Wgrad9Geom *g) {
 // out[a][b][tap] = sum_split D[split][tap][a][b]   (torch weight layout [Ca][Cb][kh][kw], fp32)
 __global__ void __launch_bounds__(256)
 wgrad_finish_kernel(const float *__restrict__ D, float *__restrict__ out, int Ca, int Cb, int ntaps, int nsplit,
-                    long total) {
+                    long total, int acc) {
     const long slab = (long)ntaps * Ca * Cb;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int tap = (int)(i % ntaps);
@@ -544,7 +544,7 @@ wgrad_finish_kernel(const float *__restrict__ D, float *__restrict__ out, int Ca
         const float *p = D + (long)tap * Ca * Cb + ab;
         float s = 0.f;
         for (int k = 0; k < nsplit; ++k) s += p[k * slab];
-        out[i] = s;
+        out[i] = acc ? out[i] + s : s;
     }
 }
 
@@ -554,7 +554,7 @@ wgrad_finish_kernel(const float *__restrict__ D, float *__restrict__ out, int Ca
 // gather form above reads one 4-byte element per lane from ntaps different planes.
 #define WF_MAX_TAPS 16
 __global__ void __launch_bounds__(256)
-wgrad_finish_tiled_kernel(const float *__restrict__ D, float *__restrict__ out, long AB, int ntaps, int nsplit) {
+wgrad_finish_tiled_kernel(const float *__restrict__ D, float *__restrict__ out, long AB, int ntaps, int nsplit, int acc) {
     __shared__ float t[64 * (WF_MAX_TAPS + 1)];
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long ab0 = blockIdx.x * 64L, ab = ab0 + l;
@@ -571,15 +571,18 @@ wgrad_finish_tiled_kernel(const float *__restrict__ D, float *__restrict__ out, 
     __syncthreads();
     const long left = AB - ab0;
     const int n = (int)(left < 64 ? left : 64) * ntaps;
-    for (int j = threadIdx.x; j < n; j += 256) out[ab0 * ntaps + j] = t[(j / ntaps) * (ntaps + 1) + j % ntaps];
+    for (int j = threadIdx.x; j < n; j += 256) {
+        const float v = t[(j / ntaps) * (ntaps + 1) + j % ntaps];
+        out[ab0 * ntaps + j] = acc ? out[ab0 * ntaps + j] + v : v;      // acc: dw += (a later use of the same parameter)
+    }
 }
 
-static void launch_wgrad_finish(const float *D, float *out, int Ca, int Cb, int ntaps, int nsplit, hipStream_t s) {
+static void launch_wgrad_finish(const float *D, float *out, int Ca, int Cb, int ntaps, int nsplit, hipStream_t s, int acc = 0) {
     const long AB = (long)Ca * Cb, elems = AB * ntaps;
     if (ntaps <= WF_MAX_TAPS && (AB + 63) / 64 <= 0x7fffffffL)
-        wgrad_finish_tiled_kernel<<<(unsigned)((AB + 63) / 64), 256, 0, s>>>(D, out, AB, ntaps, nsplit);
+        wgrad_finish_tiled_kernel<<<(unsigned)((AB + 63) / 64), 256, 0, s>>>(D, out, AB, ntaps, nsplit, acc);
     else
-        wgrad_finish_kernel<<<stream_grid(elems, 256), 256, 0, s>>>(D, out, Ca, Cb, ntaps, nsplit, elems);
+        wgrad_finish_kernel<<<stream_grid(elems, 256), 256, 0, s>>>(D, out, Ca, Cb, ntaps, nsplit, elems, acc);
 }
 
 static int plan(const ir2rgb_conv_desc *d, WgradGeom *g) {
@@ -638,8 +641,28 @@ extern "C" long ir2rgb_conv2d_wgrad_workspace_elems(const ir2rgb_conv_desc *d) {
     return (long)g.ksplit * d->kh * d->kw * g.Ca * g.Cb;
 }
 
+static int wgrad_impl(const ir2rgb_conv_desc *d, const void *x, const void *gy, float *dw, float *workspace, void *stream,
+                      int acc);
+
 extern "C" int ir2rgb_conv2d_wgrad(const ir2rgb_conv_desc *d, const void *x, const void *gy, float *dw,
                                    float *workspace, void *stream) {
+    return wgrad_impl(d, x, gy, dw, workspace, stream, 0);
+}
+
+extern "C" int ir2rgb_conv2d_wgrad_acc(const ir2rgb_conv_desc *d, const void *x, const void *gy, float *dw,
+                                       float *workspace, void *stream) {
+    return wgrad_impl(d, x, gy, dw, workspace, stream, 1);
+}
+
+extern "C" long ir2rgb_conv2d_wgrad_acc_workspace_elems(const ir2rgb_conv_desc *d) {
+    WgradGeom g;
+    int rc = plan(d, &g);
+    if (rc) return rc;
+    return (long)g.ksplit * d->kh * d->kw * g.Ca * g.Cb;       // always the one-tap kernel's slabs (see wgrad_impl)
+}
+
+static int wgrad_impl(const ir2rgb_conv_desc *d, const void *x, const void *gy, float *dw, float *workspace, void *stream,
+                      int acc) {
     WgradGeom g;
     int rc = plan(d, &g);
     if (rc) return rc;
@@ -648,7 +671,9 @@ extern "C" int ir2rgb_conv2d_wgrad(const ir2rgb_conv_desc *d, const void *x, con
     const int ntaps = d->kh * d->kw;
     const long elems = (long)ntaps * g.Ca * g.Cb;
     Wgrad9Geom g9;
-    if (use_wgrad9() && plan9(d, &g9)) {
+    // accumulate mode (a parameter used several times per pass: the discriminators) sums in the finish pass of the
+    // one-tap kernel; the nine-tap kernel's direct-write form has no such pass, so those layers take the one-tap kernel
+    if (!acc && use_wgrad9() && plan9(d, &g9)) {
         if (((uintptr_t)dw | (uintptr_t)workspace) & 15) return IR2RGB_EALIGN;
         float *dst = g9.ksplit > 1 ? workspace : dw;
         const unsigned grid9 = (unsigned)((long)g9.ksplit * (g9.Ca / 64) * (g9.Cb / 64));
@@ -669,6 +694,6 @@ extern "C" int ir2rgb_conv2d_wgrad(const ir2rgb_conv_desc *d, const void *x, con
         if (d->dtype == IR2RGB_BF16) conv_wgrad_kernel<IR2RGB_BF16, 0><<<grid, 256, 0, s>>>(U, V, workspace, g);
         else conv_wgrad_kernel<IR2RGB_F16, 0><<<grid, 256, 0, s>>>(U, V, workspace, g);
     }
-    launch_wgrad_finish(workspace, dw, g.Ca, g.Cb, ntaps, g.ksplit, s);
+    launch_wgrad_finish(workspace, dw, g.Ca, g.Cb, ntaps, g.ksplit, s, acc);
     return ir2rgb_launch_status();
 }
