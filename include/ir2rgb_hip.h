@@ -170,6 +170,17 @@ int ir2rgb_conv2d_pack_batch_run(const void *table_dev, int nentries, int nblock
 int ir2rgb_conv2d_fwd(const ir2rgb_conv_desc *d, const void *x, const void *wpacked, const float *bias, void *y,
                       float *stats_partial, void *stream);
 
+/* The same with a caller-owned workspace, which lets layers with too few output tiles for the chip split their input
+ * channels over two workgroups per tile (the 1024 -> 1024 3x3 convolutions of ResnetBlock, networks.py:556-580, at
+ * 32 x 64 and their data gradients: 128 tiles of 128 px x 128 cout for 256 CUs).  ir2rgb_conv2d_fwd_workspace_bytes:
+ * 0 = this descriptor has no use for one (pass NULL), < 0 = error.  The workspace is 16-byte aligned, must be ZERO
+ * when first used and is left ready for the next launch by every launch (tickets advance by a fixed amount per
+ * launch; the partial sums need no initialisation); launches that share one must be ordered (same stream).
+ * Results are bit-identical from launch to launch: two partial sums are added, in either order. */
+long ir2rgb_conv2d_fwd_workspace_bytes(const ir2rgb_conv_desc *d);
+int ir2rgb_conv2d_fwd_ws(const ir2rgb_conv_desc *d, const void *x, const void *wpacked, const float *bias, void *y,
+                         float *stats_partial, void *workspace, long workspace_bytes, void *stream);
+
 /* Name of the device kernel ir2rgb_conv2d_fwd launches for `d` ("conv3x3_patch_kernel",
  * "conv_igemm_kernel", "conv_igemm_classes_kernel"; "" for an invalid descriptor): for profiles. */
 const char *ir2rgb_conv2d_kernel_name(const ir2rgb_conv_desc *d);

@@ -62,6 +62,8 @@ PROTOTYPES = {
     "ir2rgb_conv2d_pack_batch_build": (c_int, [_pjob, c_int, P, c_long, _pint]),
     "ir2rgb_conv2d_pack_batch_run": (c_int, [P, c_int, c_int, c_int, P]),
     "ir2rgb_conv2d_fwd": (c_int, [_pdesc, P, P, P, P, P, P]),
+    "ir2rgb_conv2d_fwd_workspace_bytes": (c_long, [_pdesc]),
+    "ir2rgb_conv2d_fwd_ws": (c_int, [_pdesc, P, P, P, P, P, P, c_long, P]),
     "ir2rgb_conv2d_kernel_name": (ctypes.c_char_p, [_pdesc]),
     "ir2rgb_bn_finalize": (c_int, [P, c_int, c_int, c_long, P, P, P, P, c_float, c_float, P, P, P, P, c_int, P]),
     "ir2rgb_bn_finalize_ex": (c_int, [P, c_int, c_int, c_long, P, P, P, P, P, c_float, c_float, P, P, P, P, c_int, c_int, P]),

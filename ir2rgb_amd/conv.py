@@ -167,6 +167,30 @@ def _flops(desc):
     return 2.0 * desc.N * desc.Hout * desc.Wout * desc.Cout * desc.Cin * taps
 
 
+# Workspace of the split-K form of the 3x3 kernel (ir2rgb_conv2d_fwd_ws): one per (device, stream), zeroed once --
+# launches on one stream are ordered, which is what sharing it needs.  While a HIP graph is being captured a fresh
+# zeroed one is taken per launch instead (it belongs to the graph's memory pool; kernels captured on one stream may
+# replay next to kernels of ANOTHER graph captured on the same stream).
+_SPLIT_WS = {}
+
+
+def _fwd_workspace(desc, x):
+    n = getattr(desc, "_ws_bytes", None)         # (descriptors are built once per layer and shape and never edited)
+    if n is None:
+        n = desc._ws_bytes = int(_lib.lib().ir2rgb_conv2d_fwd_workspace_bytes(ctypes.byref(desc)))
+        if n < 0:
+            _lib.check(n, "conv2d_fwd_workspace_bytes")
+    if n == 0:
+        return None, 0
+    if torch.cuda.is_current_stream_capturing():
+        return torch.zeros(n, dtype=torch.uint8, device=x.device), n
+    k = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
+    ws = _SPLIT_WS.get(k)
+    if ws is None or ws.numel() < n:
+        ws = _SPLIT_WS[k] = torch.zeros(n, dtype=torch.uint8, device=x.device)
+    return ws, n
+
+
 def conv2d_fwd(desc, x, wpacked, bias=None, want_stats=False, out=None):
     """x: logical [N,Cin,H,W] channels_last half tensor.  Returns (y, stats_partial | None)."""
     if not is_nhwc(x) or x.dtype not in _TORCH2DT or _TORCH2DT[x.dtype] != desc.dtype:
@@ -180,10 +204,11 @@ def conv2d_fwd(desc, x, wpacked, bias=None, want_stats=False, out=None):
     stats = None
     if want_stats:
         stats = torch.empty((stats_rows(desc), 2, desc.Cout), dtype=torch.float32, device=x.device)
-    tok = _prof_begin(desc)
     with _lib.on_device(x):
-        rc = _lib.lib().ir2rgb_conv2d_fwd(ctypes.byref(desc), _p(x), _p(wpacked), _p(bias), _p(y), _p(stats),
-                                          _lib.current_stream(x))
+        ws, ws_bytes = _fwd_workspace(desc, x)
+        tok = _prof_begin(desc)
+        rc = _lib.lib().ir2rgb_conv2d_fwd_ws(ctypes.byref(desc), _p(x), _p(wpacked), _p(bias), _p(y), _p(stats), _p(ws), ws_bytes,
+                                             _lib.current_stream(x))
     _lib.check(rc, "conv2d_fwd")
     if tok is not None:
         _prof_end(tok, desc)

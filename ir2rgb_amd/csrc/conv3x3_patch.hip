@@ -66,20 +66,20 @@ __device__ __forceinline__ int p3_reflect(int v, int n) {
 
 // SPS = 32-channel slices per K-step (1 or 2): with 2, a step covers a whole 64-channel chunk at one ky --
 // twice the MFMA work between barriers for the small tile, whose steps are otherwise only 24 MFMAs long.
-template <int TW, int TCO, int NCW, int NLW, int ADJ, int SPS> struct P3Cfg {
-    static constexpr int TR = 2, NPX = TR * TW;
+template <int TW, int TCO, int NCW, int NLW, int ADJ, int SPS, int TR_ = 2> struct P3Cfg {
+    static constexpr int TR = TR_, NPX = TR * TW;            // pixel tile: TR rows x TW columns
     static constexpr int PWP = ((TW + 2 + 15) / 16) * 16;   // patch row pitch in entries (80 | 144)
     static constexpr int PROWI = PWP / 16;                   // DMA instructions per patch row
     static constexpr int NW1 = 3 * TCO / 16, NW = SPS * NW1; // DMA instructions for the weights of one K-step
     static constexpr int WST1 = 3 * TCO * 64, WST = SPS * WST1;   // bytes per weight stage (per slice, per step)
-    static constexpr int PBUF = 4 * PWP * 64;                // bytes per patch buffer (one slice)
-    static constexpr int NSTW = (SPS == 2 || (TW == 128 && TCO == 128)) ? 3 : 4;
+    static constexpr int PBUF = (TR + 2) * PWP * 64;         // bytes per patch buffer (one slice): TR + 2 haloed rows
+    static constexpr int NSTW = (SPS == 2 || TCO == 128 && (TW == 128 || TR > 2)) ? 3 : 4;
     static constexpr int AHEAD = NSTW - 1;
     static constexpr int WM = TCO / 64, WN = NCW / WM, PXW = NPX / WN, NI = PXW / 16;
     static constexpr int LDS = NSTW * WST + 2 * SPS * PBUF + 1024;
-    // patch rows staged with the step of phase ky: rows {0,1} | {2} | {3}; reflect-adjoint mode needs every row from
-    // the first step on (its border terms read row 2 at ky = 0), so it stages all four with ky = 0
-    static constexpr int np1(int ky) { return ADJ ? (ky == 0 ? 4 * PROWI : 0) : (ky == 0 ? 2 * PROWI : PROWI); }
+    // patch rows staged with the step of phase ky: rows {0..TR-1} | {TR} | {TR+1}; reflect-adjoint mode needs every row
+    // from the first step on (its border terms read row 2 at ky = 0), so it stages all of them with ky = 0
+    static constexpr int np1(int ky) { return ADJ ? (ky == 0 ? (TR + 2) * PROWI : 0) : (ky == 0 ? TR * PROWI : PROWI); }
     static constexpr int np(int ky) { return SPS * np1(ky); }
     static constexpr int nl(int ky) { return (NW + np(ky) + NLW - 1) / NLW; }     // DMA instructions per loader wave
     static constexpr int NLMAX = nl(0);
@@ -91,13 +91,17 @@ template <int TW, int TCO, int NCW, int NLW, int ADJ, int SPS> struct P3Cfg {
     }
 };
 
-template <int DT, int TW, int TCO, int NCW, int NLW, int PIPE, int ADJ, int SPS>
+template <int DT, int TW, int TCO, int NCW, int NLW, int PIPE, int ADJ, int SPS, int SPLIT = 1, int TR = 2>
 __global__ void __launch_bounds__((NCW + NLW) * 64, 1)
 conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Wp, const float *__restrict__ bias,
-                     uint16_t *__restrict__ Y, float *__restrict__ stats_partial, const P3Geom g) {
-    typedef P3Cfg<TW, TCO, NCW, NLW, ADJ, SPS> C;
+                     uint16_t *__restrict__ Y, float *__restrict__ stats_partial, const P3Geom g,
+                     unsigned *tickets = nullptr, float *partials = nullptr) {
+    static_assert(SPLIT == 1 || SPLIT == 2, "the hand-over adds two partial tiles (order-independent)");
+    typedef P3Cfg<TW, TCO, NCW, NLW, ADJ, SPS, TR> C;
     static_assert(SPS == 1 || (PIPE && !ADJ), "two slices per step: pipelined forward form only");
-    static_assert(!(ADJ && PIPE) || C::NI <= 2, "pipelined reflect-adjoint form: border operands must be prefetched (small tile)");
+    static_assert(TR == 2 || C::PXW == TW, "taller tiles: one pixel row per multiplying wave");
+    static_assert(!(ADJ && PIPE) || C::NI <= 2 || C::PXW % TW == 0,
+                  "pipelined reflect-adjoint form: border operands must be prefetched (registers: small tile, or whole pixel rows per wave)");
     typedef P3Half<DT> Hf;
     typedef typename Hf::frag frag;
     constexpr int NI = C::NI, MI = 4;
@@ -112,15 +116,19 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
     const int npt = g.N * g.nty * g.ntx, nct = g.Cout / TCO;
     int tile;
     {
-        const int nwg = npt * nct, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        const int nwg = npt * nct * SPLIT, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     }
+    // the SPLIT workgroups of a tile have consecutive ids: same XCD, their partial sums meet in its L2
+    const int ksplit = SPLIT > 1 ? tile % SPLIT : 0;
+    if (SPLIT > 1) tile /= SPLIT;
+    const int kcl = g.kchunks / SPLIT, kc0 = ksplit * kcl;   // this workgroup's 64-channel chunks: [kc0, kc0 + kcl)
     int pt, ct;
     if (g.cout_major) { ct = tile / npt; pt = tile - ct * npt; }
     else              { pt = tile / nct; ct = tile - pt * nct; }
     const int txi = pt % g.ntx, tyi = (pt / g.ntx) % g.nty, n = pt / (g.ntx * g.nty);
     const int y0 = tyi * C::TR, x0 = txi * TW;
-    const int NK = g.kchunks * (2 / SPS) * 3;   // K-steps: (64-channel chunk, [half,] ky)
+    const int NK = kcl * (2 / SPS) * 3;         // K-steps: (64-channel chunk, [half,] ky)
 
     p3_f32x4 acc[MI][NI];
 #pragma unroll
@@ -155,7 +163,7 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
                         v = (unsigned)((((long)co * g.kchunks) * 9 + kx) * 128 + chunk * 16);
                     } else if (id < C::NW + C::np(ky)) {
                         const int q = (id - C::NW) % (C::np1(ky) > 0 ? C::np1(ky) : 1);
-                        const int pr = ky == 0 ? q / C::PROWI : ky + 1;   // (ADJ: ky == 0 covers rows 0..3)
+                        const int pr = ky == 0 ? q / C::PROWI : TR + ky - 1;   // (ADJ: ky == 0 covers every row)
                         const int pc = (q % C::PROWI) * 16 + row16;
                         int iy = y0 - g.pad + pr, ix = x0 - g.pad + pc;
                         bool ok = pc < TW + 2;
@@ -170,7 +178,7 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
         auto issue = [&]<int KY>(std::integral_constant<int, KY>) {
             const bool live = is < NK;
             const int hs = is / 3;                       // slice (SPS == 1) or 64-channel chunk (SPS == 2) of this step
-            const int cc = SPS == 2 ? hs : hs >> 1, half0 = SPS == 2 ? 0 : hs & 1;
+            const int cc = kc0 + (SPS == 2 ? hs : hs >> 1), half0 = SPS == 2 ? 0 : hs & 1;
             const unsigned w_soff = (unsigned)((cc * 9 + KY * 3) * 128 + half0 * 64);
             const unsigned x_soff = (unsigned)((cc * 64 + half0 * 32) * 2);
             unsigned char *wdst = wring + (is % C::NSTW) * C::WST;
@@ -185,7 +193,7 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
                 } else if (id < C::NW + C::np(KY)) {
                     constexpr int NP1 = C::np1(KY) > 0 ? C::np1(KY) : 1;
                     const int qq = id - C::NW, h = qq / NP1, q = qq - h * NP1;
-                    const int slot = KY == 0 ? q : (KY + 1) * C::PROWI + q;
+                    const int slot = KY == 0 ? q : (TR + KY - 1) * C::PROWI + q;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (p3_lptr_t)(pdst + h * C::PBUF + slot * 1024), 16, v,
                                                              x_soff + (unsigned)h * 64u, 0, 0);
                 } else {
@@ -249,15 +257,16 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
         //   F(., -1), column W-2 F(., W), and the four pixels next to the corners the corner values.  Each of these is
         //   a tap of the same weights applied to a patch entry of this tile at another offset:
         //     F(-1, x)  = sum_sx Wf(+1, sx) gy(0, x+sx)    -> pixel row ty = 1 of a top tile, weights ky = 2, entries of ky = 0
-        //     F(H, x)   = sum_sx Wf(-1, sx) gy(H-1, x+sx)  -> pixel row ty = 0 of a bottom tile, weights ky = 0, entries of ky = 2
+        //     F(H, x)   = sum_sx Wf(-1, sx) gy(H-1, x+sx)  -> pixel row ty = TR-2 of a bottom tile, weights ky = 0, entries of ky = 2
         //     F(y, -1)  = sum_sy Wf(sy, +1) gy(y+sy, 0)    -> pixel tx = 1, weights kx = 2, the entry of kx = 0
         //     F(y, W)   = sum_sy Wf(sy, -1) gy(y+sy, W-1)  -> pixel tx = TW-2, weights kx = 0, the entry of kx = 2
         //   so the padded 34 x 66 output grid and the fold pass disappear.  (H even, W % TW == 0: whole tiles.)
-        const bool top = y0 == 0, bot = y0 == g.H - 2, left = x0 == 0, right = x0 + TW == g.W;
+        const bool top = y0 == 0, bot = y0 == g.H - TR, left = x0 == 0, right = x0 + TW == g.W;
         // The border operands of a step are fetched right after its barrier (their LDS latency then hides under the
         // regular taps; fetched at the point of use they cost a full LDS round trip per term on a wave that has its
         // SIMD to itself: 67.6 -> see profiles) and multiplied after the tap whose weights they use.
-        constexpr bool PRE = NI <= 2;   // (the large tile has two waves per SIMD to hide the latency and no registers to spare)
+        // (the large tile has two waves per SIMD to hide the latency and no registers to spare)
+        constexpr bool PRE = NI <= 2 || (PIPE && C::PXW % TW == 0);
         frag eb_row[3][PRE ? NI : 1], eb_l[PRE ? NI : 1], eb_r[PRE ? NI : 1];
         auto entry = [&](const unsigned char *patch, int ni, int kyoff, int kxb) -> frag {
             return *reinterpret_cast<const frag *>(patch + (bofs[ni] ^ (kxb == 0 ? 0u : (kxb == 1 ? flip1 : flip2))) + kxb * 64 + kyoff);
@@ -266,8 +275,10 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
             if constexpr (PRE) {
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
-                    const int p = wn * C::PXW + ni * 16, ty = p / TW, tx = p - ty * TW;   // wave-uniform
-                    const bool rowterm = (KY == 2 && top && ty == 1) || (KY == 0 && bot && ty == 0);
+                    // wave-uniform; tx is a compile-time constant where a wave owns whole pixel rows (unused operands then vanish)
+                    const int ty = (wn * C::PXW + ni * 16) / TW;
+                    const int tx = (C::PXW % TW == 0) ? (ni * 16) % TW : (wn * C::PXW + ni * 16) % TW;
+                    const bool rowterm = (KY == 2 && top && ty == 1) || (KY == 0 && bot && ty == TR - 2);
                     if (rowterm) {
                         const int kyoff = KY == 2 ? 0 : 2 * C::PWP * 64;
 #pragma unroll
@@ -281,13 +292,15 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
         auto border_terms = [&]<int KY>(const unsigned char *patch, std::integral_constant<int, KY>, int kx, int abuf) {
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-                const int p = wn * C::PXW + ni * 16, ty = p / TW, tx = p - ty * TW;   // wave-uniform
+                // wave-uniform; tx is a compile-time constant where a wave owns whole pixel rows (unused operands then vanish)
+                    const int ty = (wn * C::PXW + ni * 16) / TW;
+                    const int tx = (C::PXW % TW == 0) ? (ni * 16) % TW : (wn * C::PXW + ni * 16) % TW;
                 auto term = [&](frag b, int only_lane) {
                     if (only_lane >= 0 && l15 != only_lane) b = frag{};
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = Hf::mfma(fa[abuf][mi], b, acc[mi][ni]);
                 };
-                const bool rowterm = (KY == 2 && top && ty == 1) || (KY == 0 && bot && ty == 0);
+                const bool rowterm = (KY == 2 && top && ty == 1) || (KY == 0 && bot && ty == TR - 2);
                 const int rowoff = KY == 2 ? 0 : 2 * C::PWP * 64;
                 constexpr int pi = PRE ? 1 : 0;   // index helper: prefetched arrays are per ni only when PRE
                 if (rowterm) term(PRE ? eb_row[kx][ni * pi] : entry(patch, ni, rowoff, kx), -1);
@@ -304,7 +317,7 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
             int ks = 0;
             __builtin_amdgcn_s_barrier();                       // step 0 has landed
             fetch(0, wring, pbufs, 0, 0);
-            for (int cc = 0; cc < g.kchunks; ++cc) {
+            for (int cc = 0; cc < kcl; ++cc) {
                 const unsigned char *patch = pbufs + (cc & 1) * 2 * C::PBUF;
                 const unsigned char *patch_next = pbufs + ((cc + 1) & 1) * 2 * C::PBUF;
                 auto step = [&]<int KY>(std::integral_constant<int, KY>) {
@@ -344,7 +357,7 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
             if constexpr (ADJ) prefetch_terms(pbufs, std::integral_constant<int, 0>{});
             // six steps per 64-channel chunk (two 32-channel slices x ky); the fragment buffers alternate with a
             // compile-time parity P (three taps per step flip it once per step)
-            for (int cc = 0; cc < g.kchunks; ++cc) {
+            for (int cc = 0; cc < kcl; ++cc) {
                 auto step = [&]<int KY, int P, int HALF>(std::integral_constant<int, KY>, std::integral_constant<int, P>,
                                                          std::integral_constant<int, HALF>) {
                     const unsigned char *patch = pbufs + HALF * C::PBUF;          // slice 2*cc + HALF
@@ -389,7 +402,7 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
             // plain form: barrier at the top of every step (two multiplying waves per SIMD hide each other's LDS
             // latency; the pipelined form above needs 2 x (MI + NI) more fragment registers than that occupancy allows)
             int ks = 0;
-            for (int hs = 0; hs < g.kchunks * 2; ++hs) {
+            for (int hs = 0; hs < kcl * 2; ++hs) {
                 const unsigned char *patch = pbufs + (hs & 1) * C::PBUF;
                 auto step = [&]<int KY>(std::integral_constant<int, KY>) {
                     __builtin_amdgcn_s_barrier();
@@ -416,6 +429,56 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
     // so that global memory sees 16-byte stores, TCO/8 lanes per contiguous TCO*2-byte pixel row, instead of 8-byte
     // pieces 2 KB apart.
     __builtin_amdgcn_s_barrier();   // every wave is past its last LDS read / its last DMA has landed: smem is reusable
+    if constexpr (SPLIT > 1) {
+        // Hand-over between the two workgroups of this tile: [tile][split][wave][mi][ni][r][lane] floats, 256 B per store.
+        // The partial sums travel as agent-scope RELAXED atomic stores / loads (sc1: coherent across the XCDs' L2s per
+        // access) around an agent-scope ticket, with s_waitcnt vmcnt(0) between the stores and the ticket.  A release /
+        // acquire fence pair (__threadfence) would be the textbook form, but on this chip it is buffer_wbl2 + buffer_inv:
+        // a walk over the XCD's whole L2 per workgroup -- measured 104 us instead of 49 for the launch.
+        constexpr int PER = NCW * MI * NI * 4 * 64;
+        float *mine = partials + ((long)tile * SPLIT + ksplit) * PER;
+        if (!loader) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        __hip_atomic_store(mine + ((((wave * MI + mi) * NI + ni) * 4 + r) * 64 + lane), acc[mi][ni][r],
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial sums have reached the coherence point ...
+        __builtin_amdgcn_s_barrier();                      // ... every wave's have, before the ticket is drawn
+        unsigned *flag = reinterpret_cast<unsigned *>(smem);
+        if (tid == 0) *flag = __hip_atomic_fetch_add(tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_barrier();
+        const unsigned ticket = *flag;
+        if (ticket % SPLIT != SPLIT - 1) return;           // not the last arrival: done (uniform over the workgroup)
+        __builtin_amdgcn_s_barrier();                      // (the flag word is reused by the output staging below)
+        if (!loader) {
+            // (all 64 loads of a partial tile are issued before the first is consumed: they leave the L2 for the memory
+            // side, ~2 us each way -- issued in dependent groups they took longer than the K loop)
+            const float *base = partials + (long)tile * SPLIT * PER;
+            float tmp[MI][NI][4];
+            auto fetch_partial = [&](const float *src) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            tmp[mi][ni][r] = __hip_atomic_load(src + ((((wave * MI + mi) * NI + ni) * 4 + r) * 64 + lane),
+                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            };
+            fetch_partial(base + (long)(ksplit ^ 1) * PER);    // own + other: commutative, either arrival order gives the same bits
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[mi][ni][r] += tmp[mi][ni][r];
+        }
+    }
     constexpr int NCH = TCO / 8;                                    // 16-byte chunks per staged pixel row
     unsigned char *otile = smem;                                    // NPX * TCO * 2 bytes
     float *red = reinterpret_cast<float *>(smem + C::NPX * TCO * 2);   // [WN][TCO][2]
@@ -478,7 +541,19 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
             float t = 0.f;
 #pragma unroll
             for (int w = 0; w < C::WN; ++w) t += red[(w * TCO + cl) * 2 + which];
-            stats_partial[((long)(g.stats_row0 + pt) * 2 + which) * g.Cout + ct * TCO + cl] = t;
+            if constexpr (TR == 2) {
+                stats_partial[((long)(g.stats_row0 + pt) * 2 + which) * g.Cout + ct * TCO + cl] = t;
+            } else {
+                // the statistics buffer keeps the rows of the 2-row tiling (ir2rgb_conv2d_stats_rows does not depend on the
+                // variant): this tile's sums go to the first of the TR/2 rows it covers, zeros to the others
+                const int nty2 = (g.Ho + 1) / 2;
+#pragma unroll
+                for (int j = 0; j < TR / 2; ++j) {
+                    const int ty2 = tyi * (TR / 2) + j;
+                    if (ty2 < nty2)
+                        stats_partial[((long)(g.stats_row0 + (n * nty2 + ty2) * g.ntx + txi) * 2 + which) * g.Cout + ct * TCO + cl] = j == 0 ? t : 0.f;
+                }
+            }
         }
     }
 }
@@ -514,8 +589,26 @@ static int p3_min_cin() {
     return v;
 }
 
-// variant: 0 = not applicable, 1 = 2x64 px x 64 cout (8 loader waves), 2 = 2x128 px x 128 cout (4 loader waves)
-int conv3x3p_plan(const ir2rgb_conv_desc *d, P3Geom *g, int *npt_out) {
+// Split-K forms (variants 3, 4; only where the caller supplies a workspace).  IR2RGB_CONV3X3P_SPLIT=0 switches them off,
+// =3 / =4 forces one for A/B runs; default: 4 where it applies, else 3.  Measured on 1024 -> 1024 @32x64 (forward / reflect
+// adjoint, us): unsplit 47.9 / 67.2, variant 3 47.8 / 60.2, variant 4 46.3 / 56.9.  Four workgroups per tile with 8
+// multiplying waves (4x64 px x 128 cout, 8x64 px x 64 cout: the lowest L2 -> LDS traffic per flop) ran 70 us: with 24
+// K-steps per workgroup the pipeline fill and the hand-over (each way ~2 us to the memory side) outweigh the saving.
+struct P3SplitCfg { int tr, tco, ncw, split; };
+static constexpr P3SplitCfg P3_SPLIT_CFGS[2] = {
+    {2, 128, 4, 2},   // 3: 2x64 px x 128 cout, 4 multiplying waves (pipelined), two workgroups per tile
+    {4, 64, 4, 2},    // 4: 4x64 px x  64 cout, 4 multiplying waves (pipelined), two workgroups per tile
+};
+static int p3_split() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("IR2RGB_CONV3X3P_SPLIT"); v = e ? atoi(e) : 1; }
+    return v;
+}
+
+// variant: 0 = not applicable, 1 = 2x64 px x 64 cout (8 loader waves), 2 = 2x128 px x 128 cout (4 loader waves),
+// 3, 4 (only with allow_split: the caller supplies a workspace) = P3_SPLIT_CFGS: several workgroups per tile splitting the
+// input channels -- 64 x 64-per-wave tiles for layers that have too few such tiles to fill the chip
+int conv3x3p_plan(const ir2rgb_conv_desc *d, P3Geom *g, int *npt_out, bool allow_split) {
     if (!p3_enabled() || d->transposed || d->kh != 3 || d->kw != 3 || d->stride_h != 1 || d->stride_w != 1) return 0;
     if (d->pad_h != d->pad_w || d->pad_h < 0 || d->pad_h > 2 || d->out_f32) return 0;
     if (d->pad_mode < 0 || d->pad_mode > 2) return 0;
@@ -537,26 +630,75 @@ int conv3x3p_plan(const ir2rgb_conv_desc *d, P3Geom *g, int *npt_out) {
     if ((d->Cout % 128) == 0 && wr * waste(d->Wout, 128) <= 1.13 && t128 >= tmin && (!adj || d->Win % 128 == 0)) variant = 2;
     else if (wr * waste(d->Wout, 64) <= 1.13 && t64 >= tmin) variant = 1;
     if (!variant) return 0;
+    // (split forms only where variant 1 would run: ir2rgb_conv2d_stats_rows() keeps that variant's rows, see the kernel)
+    if (variant == 1 && allow_split && p3_split() && d->Cin >= 512) {
+        static const int order[2] = {4, 3};
+        for (int i = 0; i < 2; ++i) {
+            const int v = p3_split() >= 3 ? p3_split() : order[i];
+            if (v > 4) break;
+            const P3SplitCfg &c = P3_SPLIT_CFGS[v - 3];
+            const int kch = d->Cin / 64;
+            const long wgs = (long)d->N * ((d->Hout + c.tr - 1) / c.tr) * ((d->Wout + 63) / 64) * (d->Cout / c.tco) * c.split;
+            const bool ok = (d->Cout % c.tco) == 0 && (kch % c.split) == 0 && kch / c.split >= 2 && (!adj || (d->Hin % c.tr) == 0) &&
+                            waste(d->Hout, c.tr) * waste(d->Wout, 64) <= 1.13 && wgs >= tmin;
+            if (ok) { variant = v; break; }
+            if (p3_split() >= 3) break;
+        }
+    }
+    const int tr = variant >= 3 ? P3_SPLIT_CFGS[variant - 3].tr : 2;
     const int tw = variant == 2 ? 128 : 64;
     *g = P3Geom{};
     g->N = d->N; g->H = d->Hin; g->W = d->Win; g->Ho = d->Hout; g->Wo = d->Wout; g->Cin = d->Cin; g->Cout = d->Cout;
     g->pad = d->pad_h; g->pad_mode = d->pad_mode; g->act = d->act;
     g->ldx = ldx; g->ci_off = d->ci_off; g->ldy = ldy; g->co_off = d->co_off;
-    g->stats_row0 = 0; g->nty = (d->Hout + 1) / 2; g->ntx = (d->Wout + tw - 1) / tw;
+    g->stats_row0 = 0; g->nty = (d->Hout + tr - 1) / tr; g->ntx = (d->Wout + tw - 1) / tw;
     g->kchunks = d->Cin / 64;
     g->x_bytes = (unsigned)xb; g->w_bytes = (unsigned)wb;
     g->cout_major = wb > (long)d->N * d->Hin * d->Win * d->Cin * 2 ? 1 : 0;
     if (d->pad_mode == 1 && (d->pad_h >= d->Hin || d->pad_w >= d->Win)) return 0;
-    *npt_out = d->N * g->nty * g->ntx;
+    *npt_out = d->N * ((d->Hout + 1) / 2) * g->ntx;    // rows of the statistics buffer: 2-row tiles in every variant
     return variant;
 }
 
+// workspace of the split forms: [tiles] tickets (padded to 4 KB) + [tiles][split][waves][4][4][4][64] fp32 partial accumulators
+long conv3x3p_workspace_bytes(int variant, const P3Geom &g) {
+    if (variant < 3) return 0;
+    const P3SplitCfg &c = P3_SPLIT_CFGS[variant - 3];
+    const long tiles = (long)g.N * g.nty * g.ntx * (g.Cout / c.tco);
+    return ((tiles * 4 + 4095) & ~4095L) + tiles * c.split * (c.ncw * 4L * 4 * 4 * 64) * 4;
+}
+
+template <int DT, int TCO, int NCW, int PIPE, int SPLIT, int TR>
+static void p3_launch_split(bool adj, unsigned grid, const uint16_t *X, const uint16_t *W, const float *bias, uint16_t *Y,
+                            float *stats, const P3Geom &g, unsigned *tickets, float *partials, hipStream_t s) {
+    if (adj) conv3x3_patch_kernel<DT, 64, TCO, NCW, 4, PIPE, 1, 1, SPLIT, TR><<<grid, (NCW + 4) * 64, 0, s>>>(X, W, bias, Y, stats, g, tickets, partials);
+    else conv3x3_patch_kernel<DT, 64, TCO, NCW, 4, PIPE, 0, 1, SPLIT, TR><<<grid, (NCW + 4) * 64, 0, s>>>(X, W, bias, Y, stats, g, tickets, partials);
+}
+
+template <int DT>
+static void p3_launch_split_variant(int variant, bool adj, unsigned grid, const uint16_t *X, const uint16_t *W, const float *bias,
+                                    uint16_t *Y, float *stats, const P3Geom &g, unsigned *tickets, float *partials, hipStream_t s) {
+    if (variant == 3) p3_launch_split<DT, 128, 4, 1, 2, 2>(adj, grid, X, W, bias, Y, stats, g, tickets, partials, s);
+    else p3_launch_split<DT, 64, 4, 1, 2, 4>(adj, grid, X, W, bias, Y, stats, g, tickets, partials, s);
+}
+
 int conv3x3p_launch(int variant, const P3Geom &g, int dtype, const void *x, const void *wp, const float *bias, void *y,
-                    float *stats, hipStream_t s) {
+                    float *stats, hipStream_t s, void *workspace, long workspace_bytes) {
     const uint16_t *X = (const uint16_t *)x, *W = (const uint16_t *)wp;
     uint16_t *Yp = (uint16_t *)y;
     const int npt = g.N * g.nty * g.ntx;
     const bool adj = g.pad_mode == 2;
+    if (variant >= 3) {
+        if (!workspace || workspace_bytes < conv3x3p_workspace_bytes(variant, g) || ((uintptr_t)workspace & 15)) return IR2RGB_EINVAL;
+        const P3SplitCfg &c = P3_SPLIT_CFGS[variant - 3];
+        const long tiles = (long)npt * (g.Cout / c.tco);
+        unsigned *tickets = (unsigned *)workspace;
+        float *partials = (float *)((char *)workspace + ((tiles * 4 + 4095) & ~4095L));
+        const unsigned grid = (unsigned)(tiles * c.split);
+        if (dtype == IR2RGB_BF16) p3_launch_split_variant<IR2RGB_BF16>(variant, adj, grid, X, W, bias, Yp, stats, g, tickets, partials, s);
+        else p3_launch_split_variant<IR2RGB_F16>(variant, adj, grid, X, W, bias, Yp, stats, g, tickets, partials, s);
+        return ir2rgb_launch_status();
+    }
     if (variant == 2) {
         const unsigned grid = (unsigned)(npt * (g.Cout / 128));
         if (adj) {

@@ -898,9 +898,10 @@ struct P3Geom {
     int cout_major, kchunks;
     unsigned x_bytes, w_bytes;
 };
-int conv3x3p_plan(const ir2rgb_conv_desc *d, P3Geom *g, int *npt_out);
+int conv3x3p_plan(const ir2rgb_conv_desc *d, P3Geom *g, int *npt_out, bool allow_split = false);
+long conv3x3p_workspace_bytes(int variant, const P3Geom &g);
 int conv3x3p_launch(int variant, const P3Geom &g, int dtype, const void *x, const void *wp, const float *bias, void *y,
-                    float *stats, hipStream_t s);
+                    float *stats, hipStream_t s, void *workspace, long workspace_bytes);
 
 // One fp32 output channel, zero padding, 512-channel slabs, <= 16 taps: conv_dot_kernel (IR2RGB_CONV_DOT=0: GEMM tile)
 static bool conv_dot_ok(const ir2rgb_conv_desc *d) {
@@ -1135,15 +1136,31 @@ static void launch_conv(const ClassPlan &c, const uint16_t *x, const uint16_t *w
     else                             launch_conv_taps<DT, 0, 0>(c, tp, grid, x, wp, bias, y, stats, s);
 }
 
+extern "C" long ir2rgb_conv2d_fwd_workspace_bytes(const ir2rgb_conv_desc *d) {
+    if (!d) return IR2RGB_EINVAL;
+    P3Geom g3;
+    int npt3 = 0;
+    return conv3x3p_workspace_bytes(conv3x3p_plan(d, &g3, &npt3, true), g3);
+}
+
+extern "C" int ir2rgb_conv2d_fwd_ws(const ir2rgb_conv_desc *d, const void *x, const void *wpacked, const float *bias,
+                                    void *y, float *stats_partial, void *workspace, long workspace_bytes, void *stream);
+
 extern "C" int ir2rgb_conv2d_fwd(const ir2rgb_conv_desc *d, const void *x, const void *wpacked, const float *bias,
                                  void *y, float *stats_partial, void *stream) {
+    return ir2rgb_conv2d_fwd_ws(d, x, wpacked, bias, y, stats_partial, nullptr, 0, stream);
+}
+
+extern "C" int ir2rgb_conv2d_fwd_ws(const ir2rgb_conv_desc *d, const void *x, const void *wpacked, const float *bias,
+                                    void *y, float *stats_partial, void *workspace, long workspace_bytes, void *stream) {
     if (!d) return IR2RGB_EINVAL;
     if ((((uintptr_t)x | (uintptr_t)wpacked | (uintptr_t)y) & 15) != 0) return IR2RGB_EALIGN;
     {
         P3Geom g3;
         int npt3 = 0;
-        const int variant = conv3x3p_plan(d, &g3, &npt3);
-        if (variant) return conv3x3p_launch(variant, g3, d->dtype, x, wpacked, bias, y, stats_partial, as_stream(stream));
+        const int variant = conv3x3p_plan(d, &g3, &npt3, workspace != nullptr);
+        if (variant)
+            return conv3x3p_launch(variant, g3, d->dtype, x, wpacked, bias, y, stats_partial, as_stream(stream), workspace, workspace_bytes);
     }
     ClassPlan plans[4];
     int n = make_plan(d, plans);

@@ -74,7 +74,11 @@ CASES = [
     (1, 256, 64, 126, 1024, 3, 1, 2, 0, False, 0),   # data-gradient geometry: zero pad 2, output 66x128
     (1, 320, 67, 128, 192, 3, 1, 1, 0, False, 0),    # 2x64 px x 64 cout tiles (Cout % 128 != 0), zero pad, 5 K chunks
     (2, 256, 34, 64, 320, 3, 1, 1, 1, False, 0),     # 2x64 tiles, batch 2, reflect
+    # ... its split-K form (two workgroups per 2x64 px x 128 cout tile, Cin >= 512)
+    (1, 512, 52, 128, 256, 3, 1, 1, 1, False, 0),    # reflect, 4 + 4 K chunks
+    (2, 640, 35, 64, 384, 3, 1, 1, 0, False, 0),     # zero pad, batch 2, 5 + 5 K chunks, ragged last row
 ]
+SPLIT_CASES = CASES[-2:]
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -153,6 +157,8 @@ def test_hot_shape_linearity(dev):
     (1, 256, 100, 128, 256),     # 2x64 px x 64 cout tiles: every tile touches the left and right border
     (1, 256, 100, 256, 256),     # 2x128 px x 128 cout tiles
     (2, 320, 52, 64, 256),       # one column tile (left and right border in the same tile), batch 2, 5 K chunks
+    (1, 512, 52, 128, 512),      # split-K form: 2x64 px x 128 cout tiles, two workgroups each
+    (2, 640, 52, 64, 256),       # split-K form, one column tile, batch 2, 5 + 5 K chunks
 ])
 def test_reflect_adjoint_in_place(dev, dtype, case):
     """pad_mode 2 of the patch-staged kernel: the data gradient of a reflection-padded 3x3 convolution computed
@@ -181,6 +187,47 @@ def test_reflect_adjoint_in_place(dev, dtype, case):
     # the general kernel refuses the mode instead of computing something else
     small = C.make_desc((1, 64, 8, 64), 64, 3, 1, 1, C.PAD_REFLECT_ADJ, dtype)
     assert C.kernel_name(small) == ""
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", SPLIT_CASES)
+def test_split_k_form(dev, dtype, case):
+    """The split-K form of the patch-staged kernel (ir2rgb_conv2d_fwd_ws with a workspace): selected for these shapes,
+    bit-identical from launch to launch (the two partial tiles are added in whichever order the workgroups finish:
+    a + b == b + a), BatchNorm partial sums included, and equal to the unsplit form (ir2rgb_conv2d_fwd: no workspace)
+    up to the fp32 summation order."""
+    import ctypes
+    from ir2rgb_amd import conv as C, _lib
+    if os.environ.get("IR2RGB_CONV3X3P") == "0" or os.environ.get("IR2RGB_CONV3X3P_SPLIT") == "0":
+        pytest.skip("split-K form disabled by the environment")
+    N, Cin, H, W, Cout, k, stride, pad, pad_mode = case[:9]
+    g = torch.Generator(device="cpu").manual_seed(11)
+    x = torch.randn(N, Cin, H, W, generator=g).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) * (1.0 / np.sqrt(Cin * k * k))).to(dev)
+    desc = C.make_desc(x.shape, Cout, k, stride, pad, pad_mode, dtype)
+    assert C.kernel_name(desc) == "conv3x3_patch_kernel"
+    assert _lib.lib().ir2rgb_conv2d_fwd_workspace_bytes(ctypes.byref(desc)) > 0
+    wp = C.pack_weight(desc, w)
+    y0, s0 = C.conv2d_fwd(desc, x, wp, want_stats=True)
+    for _ in range(10):
+        y, s = C.conv2d_fwd(desc, x, wp, want_stats=True)
+        assert torch.equal(y, y0) and torch.equal(s, s0)
+    # the same workspace serves another shape in between (tickets advance by a fixed amount per launch)
+    other = SPLIT_CASES[0] if case is SPLIT_CASES[1] else SPLIT_CASES[1]
+    _ref_and_run(dev, dtype, *other)
+    y, s = C.conv2d_fwd(desc, x, wp, want_stats=True)
+    assert torch.equal(y, y0) and torch.equal(s, s0)
+    # unsplit form through the plain entry point
+    y1 = torch.empty_like(y0)
+    s1 = torch.empty_like(s0)
+    rc = _lib.lib().ir2rgb_conv2d_fwd(ctypes.byref(desc), C._p(x), C._p(wp), None, C._p(y1), C._p(s1), _lib.current_stream(x))
+    assert rc == 0
+    rms = y1.float().pow(2).mean().sqrt().item()
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10         # spacing of the half grid, relative, at most
+    d = (y0.float() - y1.float()).abs()
+    assert (d <= ulp * y1.float().abs() + 2e-5 * rms).all()          # the last bit of the half output (+ fp32 summation noise near 0)
+    assert (d > 0).float().mean().item() < 0.05                        # ... and rarely
+    torch.testing.assert_close(s0.sum(0), s1.sum(0), rtol=1e-5, atol=1e-4 * rms * rms * H * W)
 
 
 def test_full_size_adjoint_identities(dev):
