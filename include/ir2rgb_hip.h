@@ -128,6 +128,11 @@ typedef struct ir2rgb_conv_desc {
      * read; y holds ldy channels per pixel of which [co_off, co_off+Cout) are written.  Lets producers
      * write straight into the concatenation buffers of the FlowNet2 decoders (torch.cat, FlowNetS.py etc.) */
     int ldx, ci_off, ldy, co_off;
+    /* 1: the rows of the statistics buffer are cut per sample -- rows [n * R / N, (n + 1) * R / N) hold sample n only
+     * (R = ir2rgb_conv2d_stats_rows) -- so that BatchNorm can treat groups of samples as separate forwards (the
+     * discriminators' real / generated batches, reference discriminator.py:154-166, run as ONE convolution).  Costs
+     * partly filled pixel tiles at every sample's end; not for transposed convolutions.  0: tiles run over the batch. */
+    int stats_per_sample;
 } ir2rgb_conv_desc;
 
 /* Number of half elements of the packed weight buffer for this convolution (< 0: error). */

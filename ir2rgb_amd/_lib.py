@@ -19,7 +19,7 @@ class ConvDesc(ctypes.Structure):
     """ir2rgb_conv_desc of include/ir2rgb_hip.h."""
     _fields_ = [(n, c_int) for n in ("N", "Hin", "Win", "Cin", "Hout", "Wout", "Cout", "kh", "kw", "stride_h", "stride_w",
                                      "pad_h", "pad_w", "pad_mode", "transposed", "dtype", "act", "out_f32",
-                                     "ldx", "ci_off", "ldy", "co_off")]
+                                     "ldx", "ci_off", "ldy", "co_off", "stats_per_sample")]
 
 
 _pdesc = ctypes.POINTER(ConvDesc)

@@ -39,8 +39,9 @@ def _as_half_nhwc(g, dtype):
     return g.to(dtype).contiguous(memory_format=torch.channels_last)
 
 
-def bn_bwd(gz, y, scale, shift, mean, invstd, act):
-    """-> (gy, dgamma, dbeta).  scale None: activation-only stage (dbeta is then the bias gradient)."""
+def bn_bwd(gz, y, scale, shift, mean, invstd, act, out=None):
+    """-> (gy, dgamma, dbeta).  scale None: activation-only stage (dbeta is then the bias gradient).  ``out``: where gy
+    goes (a sample-group slice of the batch's gradient tensor, see ConvStageFn)."""
     n, ch, h, w = y.shape
     npix = n * h * w
     lib = _lib.lib()
@@ -51,7 +52,7 @@ def bn_bwd(gz, y, scale, shift, mean, invstd, act):
     partial = torch.empty((nblk * 2 + 3) * ch, dtype=torch.float32, device=dev)
     dgamma = torch.empty(ch, dtype=torch.float32, device=dev)
     dbeta = torch.empty(ch, dtype=torch.float32, device=dev)
-    gy = torch.empty_like(y, memory_format=torch.channels_last)
+    gy = out if out is not None else torch.empty_like(y, memory_format=torch.channels_last)
     with _lib.on_device(y):
         rc = lib.ir2rgb_bn_bwd(_p(gz), _p(y), _p(scale), _p(shift), _p(mean), _p(invstd), _p(gy), _p(dgamma), _p(dbeta),
                                _p(partial), npix, ch, act, _DT[y.dtype], _lib.current_stream(y))
@@ -180,7 +181,7 @@ class _PaddedBN:
             self.bn.running_var.copy_(self.running_var[:c])
 
 
-def conv_dgrad(gy, conv, spec, x_shape, weight_fn=None, tag="dgrad"):
+def conv_dgrad(gy, conv, spec, x_shape, weight_fn=None, tag="dgrad", out=None):
     """gy: grad wrt the convolution output (channels_last half, channels % 64 == 0).  ``weight_fn``
     maps conv.weight to the weight tensor the forward convolution actually used (x-expanded / padded
     forms).  Returns grad wrt the convolution input (channels_last half)."""
@@ -192,7 +193,7 @@ def conv_dgrad(gy, conv, spec, x_shape, weight_fn=None, tag="dgrad"):
         # forward was ConvTranspose2d(W[cin][cout]); adjoint = Conv2d with the same memory as [out=cin][in=cout]
         desc = C.make_desc(tuple(gy.shape), cin, (kh, kw), (sh, sw), (ph, pw), C.PAD_ZERO, dt)
         wp = L.packed_weight(conv, desc, weight_fn, tag=tag)
-        dx, _ = C.conv2d_fwd(desc, gy, wp)
+        dx, _ = C.conv2d_fwd(desc, gy, wp, out=out)
         return dx
     if sh == 1 and sw == 1:
         if spec["pad_mode"] == C.PAD_REFLECT:
@@ -203,15 +204,16 @@ def conv_dgrad(gy, conv, spec, x_shape, weight_fn=None, tag="dgrad"):
                 if C.kernel_name(dadj) == "conv3x3_patch_kernel":
                     dpack = C.make_desc(tuple(gy.shape), cin, 3, 1, 1, C.PAD_ZERO, dt)
                     wp = L.packed_weight(conv, dpack, weight_fn, tag=tag, adjoint=True)
-                    dx, _ = C.conv2d_fwd(dadj, gy, wp)
+                    dx, _ = C.conv2d_fwd(dadj, gy, wp, out=out)
                     return dx
             desc = C.make_desc(tuple(gy.shape), cin, (kh, kw), 1, (kh - 1, kw - 1), C.PAD_ZERO, dt)
             wp = L.packed_weight(conv, desc, weight_fn, tag=tag, adjoint=True)
             dxpad, _ = C.conv2d_fwd(desc, gy, wp)
-            return fold_reflect(dxpad, ph, pw) if (ph or pw) else dxpad
+            dx = fold_reflect(dxpad, ph, pw) if (ph or pw) else dxpad
+            return dx if out is None else out.copy_(dx)
         desc = C.make_desc(tuple(gy.shape), cin, (kh, kw), 1, (kh - 1 - ph, kw - 1 - pw), C.PAD_ZERO, dt)
         wp = L.packed_weight(conv, desc, weight_fn, tag=tag, adjoint=True)
-        dx, _ = C.conv2d_fwd(desc, gy, wp)
+        dx, _ = C.conv2d_fwd(desc, gy, wp, out=out)
         return dx
     # strided zero-padded convolution: adjoint = transposed convolution reading W as [in=cout][out=cin]
     if spec["pad_mode"] != C.PAD_ZERO:
@@ -221,7 +223,7 @@ def conv_dgrad(gy, conv, spec, x_shape, weight_fn=None, tag="dgrad"):
                       _DT[dt], 0, 0, 0, 0, 0, 0)
     assert 0 <= hin - hfull < sh and 0 <= win - wfull < sw, "adjoint geometry mismatch"
     wp = L.packed_weight(conv, desc, weight_fn, tag=tag)
-    dx, _ = C.conv2d_fwd(desc, gy, wp)
+    dx, _ = C.conv2d_fwd(desc, gy, wp, out=out)
     return dx
 
 
@@ -340,15 +342,21 @@ FUSED_BN = os.environ.get("IR2RGB_FUSED_BN", "1") != "0"    # bn_finalize + bn_a
 
 
 @contextlib.contextmanager
-def backward_flags(modules, flags):
+def backward_flags(modules, flags, active_groups=None):
+    """For the backward passes run inside: ``flags`` (SKIP_*) on every convolution stage of ``modules``; ``active_groups``
+    = k: of the sample groups of a batched forward (conv_stage(groups=G)) only the first k receive a gradient in this
+    pass -- the stages then work on that leading part of the batch only and leave the rest of every gradient tensor
+    unwritten (nobody reads it: the generator's pass through the discriminators never reaches the real frames)."""
     convs = [m for mod in modules for m in mod.modules() if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d))]
     for m in convs:
         m._ir2rgb_bwd = flags
+        m._ir2rgb_active = active_groups
     try:
         yield
     finally:
         for m in convs:
             m._ir2rgb_bwd = 0
+            m._ir2rgb_active = None
 
 
 # ---------------------------------------------------------------------------------------------
@@ -386,7 +394,8 @@ class ConvStageFn(Function):
             xin = x
             desc = C.make_desc(tuple(x.shape), cout_p, spec["k"], spec["stride"], spec["pad"], spec["pad_mode"],
                                dt, spec["transposed"], spec.get("output_padding", 0), act=_fused_act(spec),
-                               out_f32=spec.get("out_f32", False))
+                               out_f32=spec.get("out_f32", False),
+                               stats_per_sample=bn is not None and spec.get("groups", 1) > 1)
             wp = L.packed_weight(conv, desc, wfn, tag="wpad" if padded else "w")
         if padded and bias is not None:
             bias = _pad_dim(bias.detach(), 0, cout_p)
@@ -398,13 +407,40 @@ class ConvStageFn(Function):
             ctx.frozen = L.bn_frozen(bn, spec["training"])
             y, stats = C.conv2d_fwd(desc, xin, wp, None, want_stats=not ctx.frozen)
             bnp = _PaddedBN(bn, cout_p) if cout_p != cout else bn
-            if FUSED_BN and not ctx.frozen and spec["training"] and stats.shape[0] <= L.FUSED_BN_MAX_ROWS and cout_p % 64 == 0:
-                # few partial rows (the residual blocks): statistics and apply in one launch
-                z, scale, shift, mean, invstd = L.bn_finalize_apply(stats, desc.N * desc.Hout * desc.Wout, bnp, y, spec["act"],
-                                                                    res1, res2, bias)
+            G = spec.get("groups", 1)
+            count = desc.N * desc.Hout * desc.Wout
+            fused = FUSED_BN and not ctx.frozen and spec["training"] and cout_p % 64 == 0
+            if G == 1:
+                if fused and stats.shape[0] <= L.FUSED_BN_MAX_ROWS:
+                    # few partial rows (the residual blocks): statistics and apply in one launch
+                    z, scale, shift, mean, invstd = L.bn_finalize_apply(stats, count, bnp, y, spec["act"], res1, res2, bias)
+                else:
+                    scale, shift, mean, invstd = L.bn_finalize(stats, count, bnp, spec["training"], bias)
+                    z = L.bn_apply(y, scale, shift, spec["act"], res1, res2)
             else:
-                scale, shift, mean, invstd = L.bn_finalize(stats, desc.N * desc.Hout * desc.Wout, bnp, spec["training"], bias)
-                z = L.bn_apply(y, scale, shift, spec["act"], res1, res2)
+                # G independent forwards batched along N (the discriminators see real / generated / raw frames with the same
+                # weights): ONE convolution, then BatchNorm per sample group exactly as G separate calls would run it --
+                # statistics over the group's samples, running statistics advanced group by group
+                if desc.N % G or res1 is not None or res2 is not None:
+                    raise ValueError("conv stage: sample groups need N % groups == 0 and no residual inputs")
+                ng, rg = desc.N // G, (0 if ctx.frozen else stats.shape[0] // G)
+                z = torch.empty_like(y, memory_format=torch.channels_last)
+                vec = torch.empty((4, G, cout_p), dtype=torch.float32, device=y.device)
+                scale, shift, mean, invstd = vec[0], vec[1], vec[2], vec[3]
+                reps = L._STAT_UPDATES        # layers.repeated_forward: an int, or one count per group
+                try:
+                    for g in (spec.get("group_order") or range(G)):      # (the order the running statistics advance in)
+                        L._STAT_UPDATES = reps[g] if isinstance(reps, tuple) else reps
+                        yg, zg = y[g * ng:(g + 1) * ng], z[g * ng:(g + 1) * ng]
+                        sg = None if ctx.frozen else stats[g * rg:(g + 1) * rg]
+                        outs = (scale[g], shift[g], mean[g], invstd[g])
+                        if fused and rg <= L.FUSED_BN_MAX_ROWS:
+                            L.bn_finalize_apply(sg, count // G, bnp, yg, spec["act"], None, None, bias, out=zg, outs=outs)
+                        else:
+                            L.bn_finalize(sg, count // G, bnp, spec["training"], bias, outs=outs)
+                            L.bn_apply(yg, scale[g], shift[g], spec["act"], out=zg)
+                finally:
+                    L._STAT_UPDATES = reps
             if bnp is not bn:
                 bnp.commit(spec["training"])
         else:
@@ -427,6 +463,17 @@ class ConvStageFn(Function):
         flags = getattr(conv, "_ir2rgb_bwd", 0)
         want_params = not (flags & SKIP_PARAM_GRADS)
         want_dx = ctx.needs_input_grad[0] and not (spec["first"] and (flags & SKIP_INPUT_GRAD))
+        # sample groups of which only the leading k carry a gradient in this pass (backward_flags): work on that part
+        G, k = spec.get("groups", 1), getattr(conv, "_ir2rgb_active", None)
+        n_full = None
+        if G > 1 and k is not None and k < G:
+            if want_params:
+                raise RuntimeError("conv stage: a pass with inactive sample groups cannot produce parameter gradients")
+            n_full = y.shape[0]
+            na = n_full // G * k
+            gz, y, xin = gz[:na], y[:na], xin[:na]
+            if scale is not None and scale.dim() == 2:
+                scale, shift, mean, invstd = scale[:k], shift[:k], mean[:k], invstd[:k]
         if spec.get("out_f32", False):
             # thin fp32 output (PatchGAN logits): pad the gradient to 64 channels for the MFMA adjoint
             cout = y.shape[1]
@@ -435,7 +482,22 @@ class ConvStageFn(Function):
             dgamma = dbeta = None
         elif ctx.has_bn:
             gz = _as_half_nhwc(gz, hdt)
-            gy, dgamma, dbeta = bn_bwd(gz, y, scale, shift, mean, invstd, spec["act"] | (16 if ctx.frozen else 0))
+            act = spec["act"] | (16 if ctx.frozen else 0)
+            if scale.dim() == 1:
+                gy, dgamma, dbeta = bn_bwd(gz, y, scale, shift, mean, invstd, act)
+            else:                       # sample groups: per-group BatchNorm backward into the batch's gradient tensor
+                G = scale.shape[0]
+                ng = y.shape[0] // G
+                gy = torch.empty_like(y, memory_format=torch.channels_last)
+                dg, db = [], []
+                for g in range(G):
+                    sl = slice(g * ng, (g + 1) * ng)
+                    _, a, b = bn_bwd(gz[sl], y[sl], scale[g], shift[g], mean[g], invstd[g], act, out=gy[sl])
+                    dg.append(a)
+                    db.append(b)
+                dgamma, dbeta = torch.stack(dg).sum(0), torch.stack(db).sum(0)
+                if ctx.frozen:
+                    scale = scale[0]    # (evaluation mode: the same running statistics for every group)
             gy_thin = gy
             # training mode: BatchNorm removes the per-channel mean, the bias gradient is exactly 0 (None = zeros);
             # evaluation mode: the layer is affine in the bias, d/dbias = scale * sum g'
@@ -459,8 +521,16 @@ class ConvStageFn(Function):
                 dxe = conv_dgrad(gy, conv, sub, (n, 64, h, wout), _compose(wfn, L._xexpanded_weight(kw)), tag="dgrad_xexp")
                 dx = xexpand_bwd(dxe, ctx.x_shape[1], ctx.x_shape[3], kw, spec["stride"][1], spec["pad"][1],
                                  spec["pad_mode"])
+            elif n_full is not None:
+                # the gradient tensor keeps the full batch's shape; the inactive groups' part stays unwritten
+                dx = C.empty_nhwc(n_full, ctx.x_shape[1], ctx.x_shape[2], ctx.x_shape[3], hdt, gy.device)
+                conv_dgrad(gy, conv, spec, (gy.shape[0],) + tuple(ctx.x_shape[1:]), pad_fn, out=dx[:gy.shape[0]])
             else:
                 dx = conv_dgrad(gy, conv, spec, ctx.x_shape, pad_fn)
+            if n_full is not None and dx.shape[0] != n_full:       # (first layer: NCHW fp32 image gradient)
+                full = dx.new_empty((n_full,) + tuple(dx.shape[1:]))
+                full[:dx.shape[0]].copy_(dx)
+                dx = full
         gy = gy_thin
         dw = None
         if not want_params:
@@ -504,13 +574,15 @@ class ConvStageFn(Function):
 
 
 def conv_stage(x, conv, bn, act, pad_mode, dtype, *, first=False, stride=None, pad=None, transposed=False,
-               output_padding=0, res1=None, res2=None, fused_leaky=False, training=True, out_f32=False, fused_relu=False):
-    """Autograd-aware stage: act(bn(conv(x))) + res1 + res2 (bn may be None)."""
+               output_padding=0, res1=None, res2=None, fused_leaky=False, training=True, out_f32=False, fused_relu=False,
+               groups=1, group_order=None):
+    """Autograd-aware stage: act(bn(conv(x))) + res1 + res2 (bn may be None).  ``groups`` > 1: the batch holds that many
+    independent forwards (N / groups samples each) -- BatchNorm treats them as separate calls."""
     stride = tuple(conv.stride) if stride is None else C._pair(stride)
     pad = tuple(conv.padding) if pad is None else C._pair(pad)
     spec = dict(k=tuple(conv.kernel_size), stride=stride, pad=pad, pad_mode=pad_mode, transposed=transposed,
                 output_padding=output_padding, act=act, fused_leaky=fused_leaky, fused_relu=fused_relu, training=training, dtype=dtype,
-                first=first, out_f32=out_f32)
+                first=first, out_f32=out_f32, groups=groups, group_order=group_order)
     gamma = bn.weight if bn is not None else None
     beta = bn.bias if bn is not None else None
     return ConvStageFn.apply(x, conv.weight, conv.bias, gamma, beta, res1, res2, spec, conv, bn)

@@ -33,14 +33,14 @@ def _pair(v):
 
 
 def make_desc(x_shape, cout, k, stride, pad, pad_mode, dtype, transposed=False, output_padding=0, act=ACT_NONE,
-              out_f32=False, ldx=0, ci_off=0, ldy=0, co_off=0):
+              out_f32=False, ldx=0, ci_off=0, ldy=0, co_off=0, stats_per_sample=False):
     """x_shape = (N, Cin, H, W) logical; k / stride / pad = int or (h, w) pair."""
     n, cin, h, w = x_shape
     (kh, kw), (sh, sw), (ph, pw) = _pair(k), _pair(stride), _pair(pad)
     ho = out_size(h, kh, sh, ph, transposed, output_padding)
     wo = out_size(w, kw, sw, pw, transposed, output_padding)
     return ConvDesc(n, h, w, cin, ho, wo, cout, kh, kw, sh, sw, ph, pw, pad_mode, int(transposed), _TORCH2DT[dtype],
-                    act, int(out_f32), ldx, ci_off, ldy, co_off)
+                    act, int(out_f32), ldx, ci_off, ldy, co_off, int(stats_per_sample))
 
 
 _KERNEL_NAMES = {}

@@ -57,6 +57,7 @@ struct P3Geom {
     int stats_row0, nty, ntx;         // pixel tiles per image: nty x ntx
     int cout_major, kchunks;
     unsigned x_bytes, w_bytes;
+    int dbg;   // ablation switches for timing experiments (IR2RGB_CONV3X3P_DBG; results are garbage): 1 = no staging after the prologue, 2 = no fragment reads
 };
 
 __device__ __forceinline__ int p3_reflect(int v, int n) {
@@ -183,6 +184,7 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
             const unsigned x_soff = (unsigned)((cc * 64 + half0 * 32) * 2);
             unsigned char *wdst = wring + (is % C::NSTW) * C::WST;
             unsigned char *pdst = pbufs + (hs & 1) * SPS * C::PBUF;
+            if ((g.dbg & 1) && is >= C::AHEAD) { ++is; return; }
 #pragma unroll
             for (int j = 0; j < C::nl(KY); ++j) {
                 const int id = lw + NLW * j;             // wave-uniform
@@ -239,6 +241,7 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
         // its first LDS round trip: MFMA-busy 58 %.)
         frag fa[PIPE ? 2 : 1][MI], fb[PIPE ? 2 : 1][NI];
         auto fetch = [&](int buf, const unsigned char *wst, const unsigned char *patch, int kyoff, int kx) {
+            if (g.dbg & 2) return;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) fa[buf][mi] = *reinterpret_cast<const frag *>(wst + aofs[mi] + kx * TCO * 64);
 #pragma unroll
@@ -430,22 +433,24 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
     // pieces 2 KB apart.
     __builtin_amdgcn_s_barrier();   // every wave is past its last LDS read / its last DMA has landed: smem is reusable
     if constexpr (SPLIT > 1) {
-        // Hand-over between the two workgroups of this tile: [tile][split][wave][mi][ni][r][lane] floats, 256 B per store.
-        // The partial sums travel as agent-scope RELAXED atomic stores / loads (sc1: coherent across the XCDs' L2s per
-        // access) around an agent-scope ticket, with s_waitcnt vmcnt(0) between the stores and the ticket.  A release /
-        // acquire fence pair (__threadfence) would be the textbook form, but on this chip it is buffer_wbl2 + buffer_inv:
-        // a walk over the XCD's whole L2 per workgroup -- measured 104 us instead of 49 for the launch.
-        constexpr int PER = NCW * MI * NI * 4 * 64;
-        float *mine = partials + ((long)tile * SPLIT + ksplit) * PER;
+        // Hand-over between the two workgroups of this tile: [tile][split][wave][mi][ni][lane] float4, 1 KB per store.
+        // The partial sums travel as 16-byte sc1 (write-through) stores and sc1 loads around an agent-scope ticket, with every
+        // storing wave's s_waitcnt vmcnt(0) and the workgroup barrier between the stores and the ticket
+        // (MI355X_MICROARCH.md, inter-workgroup visibility, valid forms: one lane adds to one counter, the workgroup whose
+        // add came last consumes; hipMalloc memory, one workgroup per CU).  A release / acquire fence pair (__threadfence)
+        // would be the textbook form, but on this chip it is buffer_wbl2 + buffer_inv: a walk over the XCD's whole L2 per
+        // workgroup -- measured 104 us instead of 49 for the launch.
+        typedef __attribute__((ext_vector_type(4))) unsigned p3_u32x4;
+        constexpr int PER = NCW * MI * NI * 64 * 16;       // bytes per partial tile
+        const p3_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(partials, 0, (int)0x7fffffff, 0x00020000);
+        const unsigned mine = (unsigned)((tile * SPLIT + ksplit) * PER), other = (unsigned)((tile * SPLIT + (ksplit ^ 1)) * PER);
         if (!loader) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        __hip_atomic_store(mine + ((((wave * MI + mi) * NI + ni) * 4 + r) * 64 + lane), acc[mi][ni][r],
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p3_u32x4, acc[mi][ni]), rp,
+                                                           mine + (unsigned)((((wave * MI + mi) * NI + ni) * 64 + lane) * 16), 0, 16);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial sums have reached the coherence point ...
         __builtin_amdgcn_s_barrier();                      // ... every wave's have, before the ticket is drawn
@@ -456,27 +461,19 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
         if (ticket % SPLIT != SPLIT - 1) return;           // not the last arrival: done (uniform over the workgroup)
         __builtin_amdgcn_s_barrier();                      // (the flag word is reused by the output staging below)
         if (!loader) {
-            // (all 64 loads of a partial tile are issued before the first is consumed: they leave the L2 for the memory
-            // side, ~2 us each way -- issued in dependent groups they took longer than the K loop)
-            const float *base = partials + (long)tile * SPLIT * PER;
-            float tmp[MI][NI][4];
-            auto fetch_partial = [&](const float *src) {
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            tmp[mi][ni][r] = __hip_atomic_load(src + ((((wave * MI + mi) * NI + ni) * 4 + r) * 64 + lane),
-                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            };
-            fetch_partial(base + (long)(ksplit ^ 1) * PER);    // own + other: commutative, either arrival order gives the same bits
+            // all 16 loads are issued before the first is consumed (they are served by the memory side, ~2 us: issued in
+            // dependent groups they took longer than the K loop); own + other: commutative, either arrival order gives the
+            // same bits
+            p3_u32x4 tmp[MI][NI];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
+                    tmp[mi][ni] = __builtin_amdgcn_raw_buffer_load_b128(rp, other + (unsigned)((((wave * MI + mi) * NI + ni) * 64 + lane) * 16), 0, 16);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[mi][ni][r] += tmp[mi][ni][r];
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] += __builtin_bit_cast(p3_f32x4, tmp[mi][ni]);
         }
     }
     constexpr int NCH = TCO / 8;                                    // 16-byte chunks per staged pixel row
@@ -640,7 +637,8 @@ int conv3x3p_plan(const ir2rgb_conv_desc *d, P3Geom *g, int *npt_out, bool allow
             const int kch = d->Cin / 64;
             const long wgs = (long)d->N * ((d->Hout + c.tr - 1) / c.tr) * ((d->Wout + 63) / 64) * (d->Cout / c.tco) * c.split;
             const bool ok = (d->Cout % c.tco) == 0 && (kch % c.split) == 0 && kch / c.split >= 2 && (!adj || (d->Hin % c.tr) == 0) &&
-                            waste(d->Hout, c.tr) * waste(d->Wout, 64) <= 1.13 && wgs >= tmin;
+                            waste(d->Hout, c.tr) * waste(d->Wout, 64) <= 1.13 && wgs >= tmin &&
+                            wgs * (c.ncw * 4096L * 4) < (1L << 30);   // (partial tiles addressed through one buffer resource)
             if (ok) { variant = v; break; }
             if (p3_split() >= 3) break;
         }
@@ -655,12 +653,13 @@ int conv3x3p_plan(const ir2rgb_conv_desc *d, P3Geom *g, int *npt_out, bool allow
     g->kchunks = d->Cin / 64;
     g->x_bytes = (unsigned)xb; g->w_bytes = (unsigned)wb;
     g->cout_major = wb > (long)d->N * d->Hin * d->Win * d->Cin * 2 ? 1 : 0;
+    { static int dbg = -1; if (dbg < 0) { const char *e = getenv("IR2RGB_CONV3X3P_DBG"); dbg = e ? atoi(e) : 0; } g->dbg = dbg; }
     if (d->pad_mode == 1 && (d->pad_h >= d->Hin || d->pad_w >= d->Win)) return 0;
     *npt_out = d->N * ((d->Hout + 1) / 2) * g->ntx;    // rows of the statistics buffer: 2-row tiles in every variant
     return variant;
 }
 
-// workspace of the split forms: [tiles] tickets (padded to 4 KB) + [tiles][split][waves][4][4][4][64] fp32 partial accumulators
+// workspace of the split forms: [tiles] tickets (padded to 4 KB) + [tiles][split][waves][4][4][64] float4 partial accumulators
 long conv3x3p_workspace_bytes(int variant, const P3Geom &g) {
     if (variant < 3) return 0;
     const P3SplitCfg &c = P3_SPLIT_CFGS[variant - 3];
@@ -668,18 +667,23 @@ long conv3x3p_workspace_bytes(int variant, const P3Geom &g) {
     return ((tiles * 4 + 4095) & ~4095L) + tiles * c.split * (c.ncw * 4L * 4 * 4 * 64) * 4;
 }
 
-template <int DT, int TCO, int NCW, int PIPE, int SPLIT, int TR>
+template <int DT, int TCO, int NCW, int PIPE, int SPLIT, int TR, int NLWF = 4>
 static void p3_launch_split(bool adj, unsigned grid, const uint16_t *X, const uint16_t *W, const float *bias, uint16_t *Y,
                             float *stats, const P3Geom &g, unsigned *tickets, float *partials, hipStream_t s) {
     if (adj) conv3x3_patch_kernel<DT, 64, TCO, NCW, 4, PIPE, 1, 1, SPLIT, TR><<<grid, (NCW + 4) * 64, 0, s>>>(X, W, bias, Y, stats, g, tickets, partials);
-    else conv3x3_patch_kernel<DT, 64, TCO, NCW, 4, PIPE, 0, 1, SPLIT, TR><<<grid, (NCW + 4) * 64, 0, s>>>(X, W, bias, Y, stats, g, tickets, partials);
+    else conv3x3_patch_kernel<DT, 64, TCO, NCW, NLWF, PIPE, 0, 1, SPLIT, TR><<<grid, (NCW + NLWF) * 64, 0, s>>>(X, W, bias, Y, stats, g, tickets, partials);
 }
 
 template <int DT>
 static void p3_launch_split_variant(int variant, bool adj, unsigned grid, const uint16_t *X, const uint16_t *W, const float *bias,
                                     uint16_t *Y, float *stats, const P3Geom &g, unsigned *tickets, float *partials, hipStream_t s) {
     if (variant == 3) p3_launch_split<DT, 128, 4, 1, 2, 2>(adj, grid, X, W, bias, Y, stats, g, tickets, partials, s);
-    else p3_launch_split<DT, 64, 4, 1, 2, 4>(adj, grid, X, W, bias, Y, stats, g, tickets, partials, s);
+    else {
+        static int nlw8 = -1;
+        if (nlw8 < 0) { const char *e = getenv("IR2RGB_CONV3X3P_NLW8"); nlw8 = e ? atoi(e) : 0; }
+        if (nlw8) p3_launch_split<DT, 64, 4, 1, 2, 4, 8>(adj, grid, X, W, bias, Y, stats, g, tickets, partials, s);
+        else p3_launch_split<DT, 64, 4, 1, 2, 4>(adj, grid, X, W, bias, Y, stats, g, tickets, partials, s);
+    }
 }
 
 int conv3x3p_launch(int variant, const P3Geom &g, int dtype, const void *x, const void *wp, const float *bias, void *y,

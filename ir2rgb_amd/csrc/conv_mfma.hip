@@ -60,6 +60,7 @@ struct ConvGeom {
     // taps form an nty x ntx grid: tap (ty,tx) reads input offset (dy0 + ty*dys, dx0 + tx*dxs).
     // Pure scalar arithmetic: no table load sits between the LDS-DMA issues of the K loop.
     int ntx, dy0, dys, dx0, dxs;
+    int tpi;                  // > 0: pixel tiles are cut per sample, tpi tiles each (ir2rgb_conv_desc.stats_per_sample)
 };
 
 
@@ -152,7 +153,7 @@ conv_igemm_body(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Wp,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned P = (unsigned)g.N * g.Hsub * g.Wsub;  // host guarantees < 2^31
     const unsigned HW = (unsigned)g.Hsub * g.Wsub;
-    const int npt = (int)((P + TP - 1) / TP), nct = (g.Cout + TC - 1) / TC;
+    const int npt = g.tpi ? g.N * g.tpi : (int)((P + TP - 1) / TP), nct = (g.Cout + TC - 1) / TC;
 
     // XCD-aware bijective remap: consecutive tile ids land on one XCD (blocks b, b+8, ... share an L2).
     // Pixel-major ids (an XCD owns a run of pixel tiles and streams ALL weights through its L2) suit layers
@@ -169,6 +170,14 @@ conv_igemm_body(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Wp,
     int pt, ct;
     if (g.cout_major) { ct = tile / npt; pt = tile - ct * npt; }
     else              { pt = tile / nct; ct = tile - pt * nct; }
+    // pixels of this tile: p0 + i, valid below plim; flattened over the batch, or (tpi > 0) inside sample pimg only, so
+    // that a row of the statistics buffer never mixes samples (BatchNorm per sample group, ir2rgb_conv_desc)
+    unsigned p0 = (unsigned)pt * TP, plim = P, pimg = 0;
+    if (g.tpi) { pimg = (unsigned)(pt / g.tpi); p0 = (unsigned)(pt - (int)pimg * g.tpi) * TP; plim = HW; }
+    auto pix_decode = [&](unsigned p, unsigned &n, unsigned &rem) {
+        if (g.tpi) { n = pimg; rem = p; }
+        else { n = fdiv(p, g.div_hw); rem = p - n * HW; }
+    };
 
     // ---------------- per-thread staging roles ----------------
     const int r8 = tid >> 3, slot = tid & 7;
@@ -187,10 +196,11 @@ conv_igemm_body(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Wp,
     unsigned pbase[PROWS];       // n * Hin * Win (pixel index)
 #pragma unroll
     for (int i = 0; i < PROWS; ++i) {
-        unsigned p = (unsigned)pt * TP + r8 + 64 * i;
-        const bool v = p < P;
+        unsigned p = p0 + r8 + 64 * i;
+        const bool v = p < plim;
         p = v ? p : 0u;
-        unsigned n = fdiv(p, g.div_hw), rem = p - n * HW;
+        unsigned n, rem;
+        pix_decode(p, n, rem);
         unsigned sy = fdiv(rem, g.div_w);
         // rows past the last pixel: zero padding -> parked outside the image (zero fill);
         // reflection -> pixel 0 (harmless, never stored)
@@ -354,10 +364,11 @@ conv_igemm_body(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Wp,
     bool oval[NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-        unsigned p = (unsigned)pt * TP + wp * (TP / 4) + ni * 16 + l15;
-        oval[ni] = p < P;
+        unsigned p = p0 + wp * (TP / 4) + ni * 16 + l15;
+        oval[ni] = p < plim;
         p = oval[ni] ? p : 0u;
-        unsigned n = fdiv(p, g.div_hw), rem = p - n * HW;
+        unsigned n, rem;
+        pix_decode(p, n, rem);
         unsigned sy = fdiv(rem, g.div_w), sx = rem - sy * g.Wsub;
         opix[ni] = ((long)n * g.Hout + (sy * g.s_out_y + g.off_y)) * g.Wout + (sx * g.s_out_x + g.off_x);
     }
@@ -439,9 +450,10 @@ conv_igemm_body(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Wp,
 #pragma unroll
         for (int pass = 0; pass < TP / 32; ++pass) {
             const int prow = pass * 32 + (tid >> 4);
-            unsigned p = (unsigned)pt * TP + prow;
-            if (p < P && cok) {
-                unsigned n = fdiv(p, g.div_hw), rem = p - n * HW;
+            unsigned p = p0 + prow;
+            if (p < plim && cok) {
+                unsigned n, rem;
+                pix_decode(p, n, rem);
                 unsigned sy = fdiv(rem, g.div_w), sx = rem - sy * g.Wsub;
                 long op = ((long)n * g.Hout + (sy * g.s_out_y + g.off_y)) * g.Wout + (sx * g.s_out_x + g.off_x);
                 const uint4 v = *reinterpret_cast<const uint4 *>(otile + prow * 256 + ((c16 ^ (prow & 15)) << 4));
@@ -874,6 +886,11 @@ static int make_plan(const ir2rgb_conv_desc *d, ClassPlan plans[4]) {
         int tp = tp_all ? tp_all : tile_pixels(P, g.Cout, g.kchunks * g.ntaps);
         plans[i].tp = tp;
         plans[i].npt = (int)((P + tp - 1) / tp);
+        if (d->stats_per_sample) {          // pixel tiles cut per sample: a statistics row never mixes samples
+            if (ncls > 1) return IR2RGB_ENOSUP;
+            g.tpi = (int)(((long)g.Hsub * g.Wsub + tp - 1) / tp);
+            plans[i].npt = g.N * g.tpi;
+        }
         g.stats_row0 = row0;
         row0 += plans[i].npt;
     }
@@ -897,6 +914,7 @@ struct P3Geom {
     int stats_row0, nty, ntx;
     int cout_major, kchunks;
     unsigned x_bytes, w_bytes;
+    int dbg;
 };
 int conv3x3p_plan(const ir2rgb_conv_desc *d, P3Geom *g, int *npt_out, bool allow_split = false);
 long conv3x3p_workspace_bytes(int variant, const P3Geom &g);

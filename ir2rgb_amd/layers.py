@@ -105,8 +105,10 @@ _STAT_UPDATES = 1
 
 @contextlib.contextmanager
 def repeated_forward(times):
+    """The forwards inside stand for ``times`` identical reference forwards each (their batch statistics enter the
+    running statistics that often).  A tuple: one count per sample group of a batched forward (ConvStageFn)."""
     global _STAT_UPDATES
-    old, _STAT_UPDATES = _STAT_UPDATES, int(times)
+    old, _STAT_UPDATES = _STAT_UPDATES, (tuple(int(t) for t in times) if isinstance(times, (tuple, list)) else int(times))
     try:
         yield
     finally:
@@ -132,7 +134,7 @@ def bn_frozen(bn, training):
     return (not training) and bn.track_running_stats and bn.running_mean is not None
 
 
-def bn_finalize(stats, count, bn, training=True, conv_bias=None):
+def bn_finalize(stats, count, bn, training=True, conv_bias=None, outs=None):
     """-> (scale, shift, mean, invstd) fp32 [C] for an input that does NOT carry ``conv_bias`` (the bias of the
     convolution in front; BatchNorm cancels it, see ir2rgb_bn_finalize_ex).  Training mode: batch statistics
     from the convolution's partial sums, running statistics updated like nn.BatchNorm2d.  Evaluation mode
@@ -141,10 +143,13 @@ def bn_finalize(stats, count, bn, training=True, conv_bias=None):
     ch = bn.num_features
     dev = bn.weight.device if bn.weight is not None else stats.device
     rows = 0 if stats is None else stats.shape[0]
-    scale = torch.empty(ch, dtype=torch.float32, device=dev)
-    shift = torch.empty_like(scale)
-    mean = torch.empty_like(scale)
-    invstd = torch.empty_like(scale)
+    if outs is not None:        # caller-owned fp32 [C] vectors (a sample group's rows of ConvStageFn's [4][G][C] block)
+        scale, shift, mean, invstd = outs
+    else:
+        scale = torch.empty(ch, dtype=torch.float32, device=dev)
+        shift = torch.empty_like(scale)
+        mean = torch.empty_like(scale)
+        invstd = torch.empty_like(scale)
     track = training and bn.track_running_stats and bn.running_mean is not None
     momentum = 0.1 if bn.momentum is None else bn.momentum
     use_running = track or frozen
@@ -163,27 +168,28 @@ def bn_finalize(stats, count, bn, training=True, conv_bias=None):
 FUSED_BN_MAX_ROWS = 128      # IR2RGB_BN_FUSED_MAX_ROWS of include/ir2rgb_hip.h
 
 
-def bn_finalize_apply(stats, count, bn, y, act, res1=None, res2=None, conv_bias=None):
+def bn_finalize_apply(stats, count, bn, y, act, res1=None, res2=None, conv_bias=None, out=None, outs=None):
     """Training-mode ``bn_finalize`` + ``bn_apply`` as one launch (ir2rgb_bn_finalize_apply) for convolutions with few
     partial rows.  -> (z, scale, shift, mean, invstd), bit-identical to the two calls."""
     rows, _, ch = stats.shape
     n, _, h, w = y.shape
-    vec = torch.empty((4, ch), dtype=torch.float32, device=y.device)       # scale | shift | mean | invstd: one allocation
-    scale, shift, mean, invstd = vec[0], vec[1], vec[2], vec[3]
-    z = torch.empty_like(y, memory_format=torch.channels_last)
+    if outs is not None:
+        scale, shift, mean, invstd = outs
+    else:
+        vec = torch.empty((4, ch), dtype=torch.float32, device=y.device)   # scale | shift | mean | invstd: one allocation
+        scale, shift, mean, invstd = vec[0], vec[1], vec[2], vec[3]
+    z = out if out is not None else torch.empty_like(y, memory_format=torch.channels_last)
     if isinstance(bn, nn.Module):
         _, pw, pb, prm, prv, has_rm, momentum, eps, trs = _bn_ptrs(bn)
     else:       # a padded shadow (autograd._PaddedBN): fresh tensors every call
         pw, pb, prm, prv, has_rm = _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var), bn.running_mean is not None
         momentum, eps, trs = 0.1 if bn.momentum is None else float(bn.momentum), float(bn.eps), bn.track_running_stats
     track = trs and has_rm
-    base = vec.data_ptr()
     null = ctypes.c_void_p(0)
     with _lib.on_device(y):
         rc = _lib.lib().ir2rgb_bn_finalize_apply(_p(stats), rows, ch, int(count), pw, pb, _p(conv_bias),
                                                  prm if track else null, prv if track else null, momentum, eps,
-                                                 ctypes.c_void_p(base), ctypes.c_void_p(base + 4 * ch),
-                                                 ctypes.c_void_p(base + 8 * ch), ctypes.c_void_p(base + 12 * ch),
+                                                 _p(scale), _p(shift), _p(mean), _p(invstd),
                                                  _STAT_UPDATES, _p(y), _p(res1), _p(res2), _p(z), n * h * w, act,
                                                  _DT[y.dtype], _lib.current_stream(y))
     _lib.check(rc, "bn_finalize_apply")
@@ -199,8 +205,12 @@ def flush_bn_counters():
     """num_batches_tracked += 1 for every BatchNorm touched since the last flush -- one fused launch
     (called at the end of each generator / discriminator forward)."""
     if _PENDING_COUNTERS:
-        for k in sorted({k for _, k in _PENDING_COUNTERS}):
-            torch._foreach_add_([t for t, kk in _PENDING_COUNTERS if kk == k], k)
+        total = {}                  # per counter tensor (a batched forward touches a layer once per sample group)
+        for t, k in _PENDING_COUNTERS:
+            ent = total.setdefault(id(t), [t, 0])
+            ent[1] += k
+        for k in sorted({k for _, k in total.values()}):
+            torch._foreach_add_([t for t, kk in total.values() if kk == k], k)
         _PENDING_COUNTERS.clear()
 
 

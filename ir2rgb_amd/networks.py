@@ -446,14 +446,15 @@ class NLayerDiscriminator(nn.Module):
             self.model = _seq([m for g in groups for m in g])
 
 
-def _run_patchgan(groups, x_nchw, dtype, training):
+def _run_patchgan(groups, x_nchw, dtype, training, sample_groups=1, group_order=None):
     """groups: list of nn.Sequential ([conv, (bn), (lrelu)]).  Returns every group's output (channels_last
-    half; the last one -- the 1-channel logits -- as fp32)."""
+    half; the last one -- the 1-channel logits -- as fp32).  ``sample_groups``: see MultiScaleDiscriminator.forward."""
     g0 = groups[0]
     h = A.conv_stage(x_nchw, g0[0], None, L.ACT_NONE, C.PAD_ZERO, dtype, first=True, fused_leaky=True, training=training)
     outs = [_real(h, g0[0].out_channels)]
     for g in groups[1:-1]:
-        h = A.conv_stage(h, g[0], g[1], L.ACT_LEAKY, C.PAD_ZERO, dtype, training=training)
+        h = A.conv_stage(h, g[0], g[1], L.ACT_LEAKY, C.PAD_ZERO, dtype, training=training, groups=sample_groups,
+                         group_order=group_order)
         outs.append(_real(h, g[0].out_channels))
     outs.append(A.conv_stage(h, groups[-1][0], None, L.ACT_NONE, C.PAD_ZERO, dtype, out_f32=True, training=training))
     return outs
@@ -490,13 +491,21 @@ class MultiScaleDiscriminator(nn.Module):
         groups.append(cur)
         return groups
 
-    def forward(self, input):
+    def forward(self, input, sample_groups=1, group_order=None):
+        """``sample_groups`` = G > 1: ``input`` stacks G independent forwards along the batch axis (N / G samples each,
+        e.g. real | generated | raw frames, discriminator.py:154-166).  Every convolution then runs ONCE over the whole
+        batch -- the deep layers of a one-frame forward fill a fraction of the chip -- while BatchNorm keeps treating the
+        groups as separate calls (batch statistics per group, running statistics advanced group by group -- in
+        ``group_order`` if given, else in batch order), so each group's outputs are what its own forward would have produced."""
         if not input.is_cuda:
             raise ValueError("ir2rgb_amd discriminators run on an AMD GPU only (no CPU fallback)")
+        if input.shape[0] % sample_groups:
+            raise ValueError("MultiScaleDiscriminator: the batch is not a multiple of sample_groups")
         result = []
         x = input.float().contiguous()
         for i in range(self.num_D):
-            outs = _run_patchgan(self._groups(self.num_D - 1 - i), x, self.compute_dtype, self.training)
+            outs = _run_patchgan(self._groups(self.num_D - 1 - i), x, self.compute_dtype, self.training, sample_groups,
+                                 group_order)
             result.append(outs if self.getIntermFeat else [outs[-1]])
             if i != self.num_D - 1:
                 x = self.downsample(x)

@@ -35,6 +35,7 @@ DEFAULTS = dict(  # options/base_options.py, options/train_options.py (SURVEY se
     no_vgg=True,         # VGG19 perceptual loss off: the pretrained weights cannot be downloaded here (False: ir2rgb_amd.vgg,
                          # randomly initialised unless a torchvision state_dict is loaded into trainer.vgg_loss.vgg)
     shared_fake_forward=True,   # one netD forward on generated frames serves the D and the G loss (autograd.backward_flags)
+    batched_D=True,      # (with shared_fake_forward) real | generated | raw frames go through a discriminator as ONE batch of sample groups
     fused_adam=True,     # one-launch HIP Adam (ir2rgb_amd.optim); False = torch.optim.Adam(foreach=True)
     fused_losses=True,   # grouped HIP loss kernels (ir2rgb_amd.losses); False = the same terms through torch ops
     batched_repack=True,  # all packed weight copies refreshed by one launch after the optimizer steps (layers.WeightRepacker)
@@ -85,6 +86,39 @@ def gan_loss(pred, real):
         p = scale[-1].float()
         total = total + F.mse_loss(p, torch.full_like(p, 1.0 if real else 0.0))
     return total
+
+
+class _SplitGroupsFn(torch.autograd.Function):
+    """t [G * n, ...] -> G views [n, ...]; backward: the pieces' gradients written into ONE buffer of t's layout, zeros
+    where a piece received none (autograd's own slicing would allocate and fill a full-size zero tensor per piece and add
+    them up; materialised zero gradients would also arrive NCHW-contiguous and drag the whole buffer out of NHWC)."""
+
+    @staticmethod
+    def forward(ctx, t, G):
+        n = t.shape[0] // G
+        ctx.set_materialize_grads(False)
+        ctx.G, ctx.n = G, n
+        ctx.meta = (tuple(t.shape), t.dtype, t.device,
+                    torch.channels_last if t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) else torch.contiguous_format)
+        return tuple(t[g * n:(g + 1) * n] for g in range(G))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        if all(g is None for g in grads):
+            return None, None
+        shape, dtype, device, fmt = ctx.meta
+        out = torch.empty(shape, dtype=dtype, device=device, memory_format=fmt)
+        n = ctx.n
+        for i, g in enumerate(grads):
+            if g is None:
+                out[i * n:(i + 1) * n].zero_()
+            else:
+                out[i * n:(i + 1) * n].copy_(g)
+        return out, None
+
+
+def split_groups(t, G):
+    return _SplitGroupsFn.apply(t, G)
 
 
 @contextlib.contextmanager
@@ -401,13 +435,15 @@ class Vid2VidTrainer:
                     loss_fm = loss_fm + dw * fw * (pred_fake[i][j] - pred_real[i][j].detach()).abs().mean(dtype=torch.float32) * o["lambda_feat"]
         return loss_gan, loss_fm
 
-    def _loss_D(self, netD, real_in, fake_in, pred_real=None):
-        """Three forwards exactly as compute_loss_D (discriminator.py:154-166).  ``pred_real``: the result of
-        ``netD(real_in)`` when the caller already holds it (see image_losses)."""
+    def _loss_D(self, netD, real_in, fake_in, pred_real=None, pred_fake=None):
+        """Three forwards exactly as compute_loss_D (discriminator.py:154-166).  ``pred_real`` / ``pred_fake``: the results
+        of ``netD(real_in)`` / ``netD(fake_in)`` when the caller already holds them (see image_losses, _batched_D)."""
         if pred_real is None:
             pred_real = netD(real_in)
         shared = self.opt["shared_fake_forward"]
-        if shared:
+        if pred_fake is not None:
+            pred_fake_d = pred_fake
+        elif shared:
             with layers.repeated_forward(2):
                 pred_fake_d = pred_fake = netD(fake_in)
         else:
@@ -418,11 +454,28 @@ class Vid2VidTrainer:
             loss_D_real, loss_D_fake = out[0], out[1]
         else:
             loss_D_real, loss_D_fake = gan_loss(pred_real, True), gan_loss(pred_fake_d, False)
-        if not shared:
+        if pred_fake is None:
             with frozen(netD):
                 pred_fake = netD(fake_in)
         loss_G_GAN, loss_G_FM = self._gan_and_fm(pred_real, pred_fake)
         return loss_D_real, loss_D_fake, loss_G_GAN, loss_G_FM
+
+    def _batched_D(self, netD, inputs, repeats, order=None):
+        """``netD`` on several inputs as ONE batch of sample groups (MultiScaleDiscriminator.forward): every convolution
+        and every weight gradient runs once per layer instead of once per input, BatchNorm sees each input as the
+        separate forward it is in the reference (``repeats[g]``: how many reference forwards group g stands for, i.e.
+        how often its batch statistics enter the running statistics; ``order``: the order the groups' statistics enter
+        them in).  Callers put the generated frames FIRST: the generator's backward pass then works on the leading
+        groups only (autograd.backward_flags(active_groups=...)).  -> one prediction pyramid per input."""
+        G = len(inputs)
+        with layers.repeated_forward(tuple(repeats)):
+            out = netD(torch.cat(inputs, 0), sample_groups=G, group_order=order)
+        preds = [[[] for _ in out] for _ in range(G)]
+        for i, scale in enumerate(out):
+            for t in scale:
+                for g, piece in enumerate(split_groups(t, G)):
+                    preds[g][i].append(piece)
+        return preds
 
     def image_losses(self, real_B, fake_B, fake_B_raw, real_A, real_B_prev, fake_B_prev, flow, weight, flow_ref, conf_ref):
         o = self.opt
@@ -450,10 +503,15 @@ class Vid2VidTrainer:
         # evaluated once here and counted twice (BatchNorm running statistics advance twice as well;
         # reference call sites discriminator.py:134 and :143).
         real_in = torch.cat((real_A, real_B), 1)
-        with layers.repeated_forward(2):
-            pred_real = self.netD(real_in)
-        d_real, d_fake, g_gan, g_fm = self._loss_D(self.netD, real_in, torch.cat((real_A, fake_B), 1), pred_real)
-        d_real2, d_fake2, g_gan2, g_fm2 = self._loss_D(self.netD, real_in, torch.cat((real_A, fake_B_raw), 1), pred_real)
+        fake_in, raw_in = torch.cat((real_A, fake_B), 1), torch.cat((real_A, fake_B_raw), 1)
+        if o["batched_D"] and o["shared_fake_forward"]:
+            pred_fake, pred_raw, pred_real = self._batched_D(self.netD, [fake_in, raw_in, real_in], (2, 2, 2), (2, 0, 1))
+        else:
+            with layers.repeated_forward(2):
+                pred_real = self.netD(real_in)
+            pred_fake = pred_raw = None
+        d_real, d_fake, g_gan, g_fm = self._loss_D(self.netD, real_in, fake_in, pred_real, pred_fake)
+        d_real2, d_fake2, g_gan2, g_fm2 = self._loss_D(self.netD, real_in, raw_in, pred_real, pred_raw)
         L["D_real"], L["D_fake"] = d_real + d_real2, d_fake + d_fake2
         L["G_GAN"], L["G_GAN_Feat"] = g_gan + g_gan2, g_fm + g_fm2
         return L
@@ -465,7 +523,11 @@ class Vid2VidTrainer:
         fl = (flow_ref / 20).reshape(b, -1, h, w)
         real_in = torch.cat([real_B.reshape(b, -1, h, w), fl], 1)
         fake_in = torch.cat([fake_B.reshape(b, -1, h, w), fl], 1)
-        d_real, d_fake, g_gan, g_fm = self._loss_D(self.netD_T[s], real_in, fake_in)
+        if self.opt["batched_D"] and self.opt["shared_fake_forward"]:
+            pred_fake, pred_real = self._batched_D(self.netD_T[s], [fake_in, real_in], (2, 1), (1, 0))
+            d_real, d_fake, g_gan, g_fm = self._loss_D(self.netD_T[s], real_in, fake_in, pred_real, pred_fake)
+        else:
+            d_real, d_fake, g_gan, g_fm = self._loss_D(self.netD_T[s], real_in, fake_in)
         return {"D_T_real": d_real, "D_T_fake": d_fake, "G_T_GAN": g_gan, "G_T_GAN_Feat": g_fm}
 
     # ------------------------------------------------------------------ temporal frame bookkeeping
@@ -541,7 +603,9 @@ class Vid2VidTrainer:
         # discriminators' passes (parameters only); without sharing the flags are no-ops
         # (inputs=...: the engine then runs only the nodes that lead to those tensors, so the
         # discriminators' passes never enter the generator graph)
-        with autograd.backward_flags(d_nets if shared else [], autograd.SKIP_PARAM_GRADS):
+        batched = shared and self.opt["batched_D"]
+        with autograd.backward_flags([self.netD] if shared else [], autograd.SKIP_PARAM_GRADS, 2 if batched else None), \
+                autograd.backward_flags(self.netD_T if shared else [], autograd.SKIP_PARAM_GRADS, 1 if batched else None):
             loss_G.backward(retain_graph=shared, inputs=g_inputs)
         self.grads_G.all_reduce_async(self.world)
         with autograd.backward_flags(d_nets if shared else [], autograd.SKIP_INPUT_GRAD):

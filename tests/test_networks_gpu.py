@@ -326,3 +326,81 @@ def test_fused_bn_finalize_apply_is_bit_identical(dev, dtype, shape):
     for a, b in zip(*outs):
         assert torch.equal(a, b)
     assert torch.isfinite(outs[0][0].float()).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(1, 6, 70, 90), (2, 13, 64, 96)])
+def test_discriminator_sample_groups_equal_separate_forwards(dev, dtype, shape):
+    """MultiScaleDiscriminator.forward(cat(inputs), sample_groups=G) -- one convolution per layer over the batch, BatchNorm
+    per group -- against G separate forwards of an identical copy (the form of reference discriminator.py:154-166):
+    per-group outputs, running statistics (advanced group by group, with per-group repeat counts), parameter and input
+    gradients.  70 x 90 frames: the deep feature maps (e.g. 10 x 13 pixels) do not fill a pixel tile, so the per-sample
+    tiling of the statistics rows (ir2rgb_conv_desc.stats_per_sample) is what keeps the groups apart."""
+    import copy
+    from ir2rgb_amd import layers as L, networks as N
+    torch.manual_seed(3)
+    D1 = N.build_discriminator_module(shape[1], 64, 3, "batch", 2, True).to(dev).train()
+    D1.compute_dtype = dtype
+    D2 = copy.deepcopy(D1)
+    reps = (2, 1, 2)
+    xs1 = [torch.randn(*shape, device=dev, requires_grad=True) for _ in reps]
+    xs2 = [x.detach().clone().requires_grad_(True) for x in xs1]
+    wts = (1.0, -0.7, 0.4)
+
+    def loss_of(outs, w):
+        return w * sum((t.float() * t.float()).mean() + t.float().mean() for scale in outs for t in scale)
+
+    sep = []
+    for x, r in zip(xs1, reps):
+        with L.repeated_forward(r):
+            sep.append(D1(x))
+    sum(loss_of(o, w) for o, w in zip(sep, wts)).backward()
+    with L.repeated_forward(reps):
+        out = D2(torch.cat(xs2, 0), sample_groups=len(reps))
+    n = shape[0]
+    bat = [[[t[g * n:(g + 1) * n] for t in scale] for scale in out] for g in range(len(reps))]
+    sum(loss_of(o, w) for o, w in zip(bat, wts)).backward()
+
+    def rel(a, b):
+        return ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-20)).item()
+
+    tol = 3e-3 if dtype == torch.float16 else 2e-2
+    for g in range(len(reps)):
+        for s1, s2 in zip(sep[g], bat[g]):
+            for a, b in zip(s1, s2):
+                assert a.shape == b.shape and rel(b, a) <= tol, (g, rel(b, a))
+    for (k, b1), (_, b2) in zip(D1.named_buffers(), D2.named_buffers()):
+        if "num_batches" in k:
+            assert torch.equal(b1, b2), k
+        else:
+            assert rel(b2, b1) <= 1e-3, (k, rel(b2, b1))
+    gtol = 2e-2 if dtype == torch.float16 else 8e-2
+    for (k, p1), (_, p2) in zip(D1.named_parameters(), D2.named_parameters()):
+        if p1.grad is None or p2.grad is None:      # the bias of a convolution in front of BatchNorm: exactly zero, left unset
+            assert p1.grad is None and p2.grad is None, k
+            continue
+        assert rel(p2.grad, p1.grad) <= gtol, (k, rel(p2.grad, p1.grad))
+    for x1, x2 in zip(xs1, xs2):
+        assert rel(x2.grad, x1.grad) <= gtol, rel(x2.grad, x1.grad)
+
+
+def test_discriminator_inactive_sample_groups(dev):
+    """The generator's pass through a batched discriminator forward: only the leading groups (generated frames) carry a
+    gradient; with autograd.backward_flags(active_groups=2) the stages work on that part of the batch only.  Input
+    gradients of the active groups == those of the unrestricted pass, which computes the third group's zeros as well."""
+    from ir2rgb_amd import autograd as A, layers as L, networks as N
+    torch.manual_seed(5)
+    D = N.build_discriminator_module(6, 64, 3, "batch", 2, True).to(dev).train()
+    D.compute_dtype = torch.float16
+    grads = []
+    for active in (None, 2):
+        xs = [torch.randn(1, 6, 70, 90, generator=torch.Generator().manual_seed(g)).to(dev).requires_grad_(g < 2) for g in range(3)]
+        with L.repeated_forward((2, 2, 2)):
+            out = D(torch.cat(xs, 0), sample_groups=3, group_order=(2, 0, 1))
+        loss = sum((t[:2].float() * t[:2].float()).mean() for scale in out for t in scale)      # groups 0 and 1 only
+        with A.backward_flags([D], A.SKIP_PARAM_GRADS, active):
+            loss.backward()
+        assert all(p.grad is None for p in D.parameters())
+        grads.append([x.grad.clone() for x in xs[:2]])
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)

@@ -28,7 +28,9 @@ def bp(loss_G, loss_D, loss_D_T, g_inputs=None):
     d_nets = [self.netD] + self.netD_T
     if g_inputs is None and shared: g_inputs = self.grads_G.params
     ev("<backward_G")
-    with autograd.backward_flags(d_nets if shared else [], autograd.SKIP_PARAM_GRADS):
+    batched = shared and self.opt["batched_D"]
+    with autograd.backward_flags([self.netD] if shared else [], autograd.SKIP_PARAM_GRADS, 2 if batched else None), \
+            autograd.backward_flags(self.netD_T if shared else [], autograd.SKIP_PARAM_GRADS, 1 if batched else None):
         loss_G.backward(retain_graph=shared, inputs=g_inputs)
     ev(">backward_G")
     self.grads_G.all_reduce_async(self.world)

@@ -5,7 +5,7 @@ Phases are delimited in the trace by marker kernels (torch special functions nob
 import os, sys, collections, csv
 MARK = collections.OrderedDict([("reference_flows", "bessel_j0"), ("generate", "bessel_j1"), ("image_losses", "bessel_y0"),
                                 ("temporal_losses", "bessel_y1"), ("backward_G", "modified_bessel_i0"), ("backward_D", "modified_bessel_i1"),
-                                ("backward_DT", "modified_bessel_k0"), ("optimizer_steps", "modified_bessel_k1"), ("end", "spherical_bessel_j0")])
+                                ("backward_DT", "modified_bessel_k0"), ("optimizer_steps", "modified_bessel_k1"), ("end", "erfcx")])
 if sys.argv[1] == "run":
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch
@@ -33,7 +33,9 @@ if sys.argv[1] == "run":
         d_nets = [self.netD] + self.netD_T
         if g_inputs is None and shared: g_inputs = self.grads_G.params
         mark("backward_G")
-        with autograd.backward_flags(d_nets if shared else [], autograd.SKIP_PARAM_GRADS):
+        batched = shared and self.opt["batched_D"]
+        with autograd.backward_flags([self.netD] if shared else [], autograd.SKIP_PARAM_GRADS, 2 if batched else None), \
+                autograd.backward_flags(self.netD_T if shared else [], autograd.SKIP_PARAM_GRADS, 1 if batched else None):
             loss_G.backward(retain_graph=shared, inputs=g_inputs)
         self.grads_G.all_reduce_async(self.world)
         with autograd.backward_flags(d_nets if shared else [], autograd.SKIP_INPUT_GRAD):
