@@ -67,6 +67,18 @@ int ir2rgb_correlation_bwd(const float *in1, const float *in2, const float *gout
                            int N, int C, int H, int W, int pad_size, int kernel_size, int max_displacement,
                            int stride1, int stride2, void *stream);
 
+/* The cost volume of FlowNetC as it sits in the FlowNet2 pipeline (reference FlowNetC.py:27, :101-103: Correlation(pad 20,
+ * kernel 1, max displacement 20, stride1 1, stride2 2) followed by LeakyReLU(0.1) and the concatenation with conv_redir):
+ * a, b = half-precision NHWC feature maps [N][H][W][lda / ldb], channels [offa, offa+C) / [offb, offb+C) -- the outputs of
+ * conv3 as ir2rgb_conv2d_fwd leaves them.  out_mode 0: out = fp32 [N][441][H][W], the layout of ir2rgb_correlation_fwd;
+ * out_mode 1: out = half NHWC [N][H][W][ldo], channels [offo, offo+441) = LeakyReLU_slope(correlation) (slope 1: none).
+ * Products of half inputs are exact in fp32; the result differs from ir2rgb_correlation_fwd on the same (half-rounded)
+ * inputs only by the order of the fp32 additions.  Banded MFMA products (correlation_mfma.hip).  C in {128, 256},
+ * W <= 128, otherwise IR2RGB_ENOSUP (use ir2rgb_correlation_fwd). */
+int ir2rgb_correlation_nhwc_half(const void *a, int lda, int offa, const void *b, int ldb, int offb, void *out,
+                                 int out_mode, int ldo, int offo, float slope, int N, int C, int H, int W, int dtype,
+                                 void *stream);
+
 /* Flow warp forward.  img [N,C,H,W], flow [N,2,H,W] (pixels; channel 0 = dx, 1 = dy)
  * -> out [N,C,H,W].  kernel_size must be 1 (the only value the reference passes; larger
  * values make its kernel read out of bounds).

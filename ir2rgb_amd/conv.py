@@ -135,11 +135,11 @@ def _prof_key(desc):
     return (desc.Cin, desc.Hin, desc.Win, desc.Cout, desc.kh, desc.kw, desc.stride_h, desc.pad_mode, desc.transposed)
 
 
-def _prof_begin(desc):
+def _prof_begin(desc, tag=None):
     prof = PROFILE
     if prof is None or SIDE_BUSY or torch.cuda.is_current_stream_capturing():
         return None   # (events recorded while a HIP graph is being captured are graph nodes, not timers)
-    key = _prof_key(desc)
+    key = _prof_key(desc) if tag is None else _prof_key(desc) + (tag,)
     only = prof.get("only")
     if only is not None and only != key:
         return None
@@ -148,13 +148,13 @@ def _prof_begin(desc):
     return prof, key, e0
 
 
-def _prof_end(tok, desc):
+def _prof_end(tok, desc, name=None):
     prof, key, e0 = tok
     e1 = torch.cuda.Event(enable_timing=True)
     e1.record()
     rec = prof.setdefault("shapes", {}).get(key)
     if rec is None:
-        name = _lib.lib().ir2rgb_conv2d_kernel_name(ctypes.byref(desc)).decode()
+        name = name or _lib.lib().ir2rgb_conv2d_kernel_name(ctypes.byref(desc)).decode()
         rec = prof["shapes"][key] = {"flops": _flops(desc), "events": [], "kernel": name}
     rec["events"].append((e0, e1))
 
@@ -240,7 +240,10 @@ def conv2d_wgrad(desc, x, gy, out=None, accumulate=False):
         dw = torch.empty(shape, dtype=torch.float32, device=x.device)
     with _lib.on_device(x):
         fn = lib.ir2rgb_conv2d_wgrad_acc if accumulate else lib.ir2rgb_conv2d_wgrad
+        tok = _prof_begin(desc, "wgrad") if PROFILE is not None else None
         rc = fn(ctypes.byref(desc), _p(x), _p(gy), _p(dw), _p(ws), _lib.current_stream(x))
+        if tok is not None:
+            _prof_end(tok, desc, "conv_wgrad")
     _lib.check(rc, "conv2d_wgrad")
     if accumulate:
         return None

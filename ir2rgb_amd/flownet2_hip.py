@@ -145,6 +145,28 @@ def put_nchw(x_nchw, yv, act=0):
     _lib.check(rc, "nchw_f32_to_nhwc_half_slice")
 
 
+def corr_nhwc(mod, av, bv, yv, slope):
+    """FlowNetC's cost volume (Correlation(20, 1, 20, 1, 2), FlowNetC.py:27) + LeakyReLU straight from the two NHWC half
+    feature maps into a channel slice of ``yv.buf`` (ir2rgb_correlation_nhwc_half: banded MFMA products).  False when the
+    operator's parameters or the shape are outside what that kernel covers."""
+    cfg = tuple(getattr(mod, k, None) for k in ("pad_size", "kernel_size", "max_displacement", "stride1", "stride2"))
+    if cfg != (20, 1, 20, 1, 2) or getattr(mod, "corr_multiply", 1) != 1 or yv.ch != 441 or av.ch != bv.ch:
+        return False
+    import os
+    if os.environ.get("IR2RGB_CORR_MFMA", "1") == "0":
+        return False
+    n = av.n
+    h, w = av.hw
+    with _lib.on_device(av.buf):
+        rc = _lib.lib().ir2rgb_correlation_nhwc_half(_p(av.buf), av.ld, av.off, _p(bv.buf), bv.ld, bv.off, _p(yv.buf), 1, yv.ld,
+                                                     yv.off, float(slope), n, av.ch, h, w, _DT[av.buf.dtype],
+                                                     _lib.current_stream(av.buf))
+    if rc == -2:        # IR2RGB_ENOSUP
+        return False
+    _lib.check(rc, "correlation_nhwc_half")
+    return True
+
+
 def flow_up(flow, mod, yv):
     """ConvTranspose2d(2,2,4,2,1) of a 2-channel fp32 flow, written into a 2-channel slice of ``yv.buf``."""
     n, _, h, w = flow.shape
@@ -216,10 +238,11 @@ def flownetc(net, x, dtype):
         c2 = conv(c1, net.conv2[0], dec.skip_view(2) if skip else _dense(n, 128, H // 4, W // 4, dtype, dev), LEAKY01)
         feats.append(conv(c2, net.conv3[0], _dense(n, 256, H // 8, W // 8, dtype, dev), LEAKY01))
     a3, b3 = feats
-    cost = net.corr(L.to_nchw_f32(a3.buf), L.to_nchw_f32(b3.buf))                 # hand-written cost volume, fp32
     merged = new_buf(n, 512, H // 8, W // 8, dtype, dev)                           # [redir 32 | corr 441 | pad]
     conv(a3, net.conv_redir[0], View(merged, 0, 32), LEAKY01)
-    put_nchw(cost, View(merged, 32, 441), act=LEAKY01)                             # corr_activation fused
+    if not corr_nhwc(net.corr, a3, b3, View(merged, 32, 441), 0.1):                # MFMA cost volume + corr_activation
+        cost = net.corr(L.to_nchw_f32(a3.buf), L.to_nchw_f32(b3.buf))             # (shapes it does not cover: scalar kernel, fp32)
+        put_nchw(cost, View(merged, 32, 441), act=LEAKY01)
     c3 = conv(View(merged, 0, 473), net.conv3_1[0], dec.skip_view(3), LEAKY01)
     c4 = conv(conv(c3, net.conv4[0], _dense(n, 512, H // 16, W // 16, dtype, dev), LEAKY01), net.conv4_1[0], dec.skip_view(4), LEAKY01)
     c5 = conv(conv(c4, net.conv5[0], _dense(n, 512, H // 32, W // 32, dtype, dev), LEAKY01), net.conv5_1[0], dec.skip_view(5), LEAKY01)

@@ -239,3 +239,41 @@ def test_resample_channelnorm_full_size_properties(dev):
     n = ChannelNorm()(img)
     torch.testing.assert_close(ChannelNorm()(img * -3.0), n * 3.0, atol=1e-5, rtol=1e-6)
     torch.testing.assert_close(n, img.pow(2).sum(1, keepdim=True).sqrt(), atol=1e-6, rtol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,C,H,W,lda,offa", [(1, 256, 8, 128, 256, 0), (2, 128, 9, 38, 192, 64), (1, 256, 5, 21, 256, 0),
+                                                (1, 256, 24, 96, 320, 64)])
+def test_correlation_nhwc_half_vs_oracle(dev, dtype, N, C, H, W, lda, offa):
+    """ir2rgb_correlation_nhwc_half (banded MFMA products on half NHWC feature maps, the form FlowNetC's cost volume takes in
+    this package's FlowNet2) against the C oracle of the reference operator on the same half-rounded inputs: products are
+    exact, only the order of the fp32 sums differs.  Both output forms: fp32 planes (the operator's layout) and the half
+    NHWC channel slice with LeakyReLU(0.1) that conv3_1 reads.  Odd widths, channel-slice views, rows and columns whose
+    displaced partner lies outside the image."""
+    import ctypes
+    from ir2rgb_amd import _lib, conv as CV
+    rng = np.random.default_rng(C + H + W)
+    fa = torch.from_numpy(rng.standard_normal((N, C, H, W)).astype(np.float32)).to(dev).to(dtype)
+    fb = torch.from_numpy(rng.standard_normal((N, C, H, W)).astype(np.float32)).to(dev).to(dtype)
+    bufa = torch.zeros((N, lda, H, W), dtype=dtype, device=dev).contiguous(memory_format=torch.channels_last)
+    bufb = torch.zeros((N, C, H, W), dtype=dtype, device=dev).contiguous(memory_format=torch.channels_last)
+    bufa[:, offa:offa + C] = fa
+    bufb[:] = fb
+    ref = O.correlation_fwd(fa.float().cpu().numpy(), fb.float().cpu().numpy(), 20, 1, 20, 1, 2)
+    lib = _lib.lib()
+    dt = CV._TORCH2DT[dtype]
+    out = torch.full((N, 441, H, W), float("nan"), dtype=torch.float32, device=dev)
+    rc = lib.ir2rgb_correlation_nhwc_half(CV._p(bufa), lda, offa, CV._p(bufb), C, 0, CV._p(out), 0, 0, 0, 1.0, N, C, H, W, dt,
+                                          _lib.current_stream(out))
+    assert rc == 0
+    close(out, ref, atol=2e-6 * np.sqrt(C))
+    # half NHWC slice + LeakyReLU(0.1) into channels [32, 473) of a 512-channel buffer; the other channels stay untouched
+    merged = torch.full((N, 512, H, W), 7.0, dtype=dtype, device=dev).contiguous(memory_format=torch.channels_last)
+    rc = lib.ir2rgb_correlation_nhwc_half(CV._p(bufa), lda, offa, CV._p(bufb), C, 0, CV._p(merged), 1, 512, 32, 0.1, N, C, H, W, dt,
+                                          _lib.current_stream(out))
+    assert rc == 0
+    want = torch.nn.functional.leaky_relu(torch.from_numpy(ref).to(dev), 0.1).to(dtype)
+    got = merged[:, 32:473]
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    assert ((got.float() - want.float()).abs() <= ulp * want.float().abs() + 1e-6).all()
+    assert (merged[:, :32] == 7.0).all() and (merged[:, 473:] == 7.0).all()
