@@ -178,10 +178,10 @@ def main():
     elapsed = float(t.item())
 
     def traffic_of(key):
-        """HBM-side bytes per launch from the committed PMC passes (profiles/r01_dominant_conv_traffic.json); None
+        """HBM-side bytes per launch from the committed PMC passes (profiles/r02_dominant_conv_traffic.json); None
         for a shape they do not cover.  (PMC counters cannot be collected inside this process.)"""
         try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_dominant_conv_traffic.json")) as f:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_dominant_conv_traffic.json")) as f:
                 return json.load(f)["shapes"].get(",".join(str(int(v)) for v in key))
         except OSError:
             return None
