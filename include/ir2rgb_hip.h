@@ -294,7 +294,8 @@ int ir2rgb_bn_bwd_blocks(long npix, int C);
  *   gy = scale * (g' - dbeta/n - yhat*dgamma/n),  yhat = (y-mean)*invstd.
  * With scale == NULL (no norm layer): gy = gz * act'(y) and dbeta = sum gy (the bias gradient).
  * act: 0 none, 1 ReLU, 2 LeakyReLU(0.2); act | 16: the statistics were frozen (evaluation-mode BatchNorm,
- * ir2rgb_bn_finalize_ex(frozen)): gy = scale * g', dgamma / dbeta as above.  gy may alias gz. */
+ * ir2rgb_bn_finalize_ex(frozen)): gy = scale * g', dgamma / dbeta as above; act | 32: dgamma / dbeta are ADDED to what the
+ * two vectors hold (the later sample groups of a layer whose batch is several independent forwards).  gy may alias gz. */
 int ir2rgb_bn_bwd(const void *gz, const void *y, const float *scale, const float *shift, const float *mean,
                   const float *invstd, void *gy, float *dgamma, float *dbeta, float *partial, long npix, int C,
                   int act, int dtype, void *stream);

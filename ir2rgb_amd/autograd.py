@@ -39,9 +39,10 @@ def _as_half_nhwc(g, dtype):
     return g.to(dtype).contiguous(memory_format=torch.channels_last)
 
 
-def bn_bwd(gz, y, scale, shift, mean, invstd, act, out=None):
+def bn_bwd(gz, y, scale, shift, mean, invstd, act, out=None, params=None):
     """-> (gy, dgamma, dbeta).  scale None: activation-only stage (dbeta is then the bias gradient).  ``out``: where gy
-    goes (a sample-group slice of the batch's gradient tensor, see ConvStageFn)."""
+    goes (a sample-group slice of the batch's gradient tensor, see ConvStageFn); ``params`` = (dgamma, dbeta) of an earlier
+    group of the same layer: this group's are added to them in the kernel (act | 32)."""
     n, ch, h, w = y.shape
     npix = n * h * w
     lib = _lib.lib()
@@ -50,8 +51,12 @@ def bn_bwd(gz, y, scale, shift, mean, invstd, act, out=None):
         _lib.check(nblk, "bn_bwd_blocks")
     dev = y.device
     partial = torch.empty((nblk * 2 + 3) * ch, dtype=torch.float32, device=dev)
-    dgamma = torch.empty(ch, dtype=torch.float32, device=dev)
-    dbeta = torch.empty(ch, dtype=torch.float32, device=dev)
+    if params is not None:
+        dgamma, dbeta = params
+        act |= 32
+    else:
+        dgamma = torch.empty(ch, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(ch, dtype=torch.float32, device=dev)
     gy = out if out is not None else torch.empty_like(y, memory_format=torch.channels_last)
     with _lib.on_device(y):
         rc = lib.ir2rgb_bn_bwd(_p(gz), _p(y), _p(scale), _p(shift), _p(mean), _p(invstd), _p(gy), _p(dgamma), _p(dbeta),
@@ -489,13 +494,11 @@ class ConvStageFn(Function):
                 G = scale.shape[0]
                 ng = y.shape[0] // G
                 gy = torch.empty_like(y, memory_format=torch.channels_last)
-                dg, db = [], []
+                params = None
                 for g in range(G):
                     sl = slice(g * ng, (g + 1) * ng)
-                    _, a, b = bn_bwd(gz[sl], y[sl], scale[g], shift[g], mean[g], invstd[g], act, out=gy[sl])
-                    dg.append(a)
-                    db.append(b)
-                dgamma, dbeta = torch.stack(dg).sum(0), torch.stack(db).sum(0)
+                    _, dgamma, dbeta = bn_bwd(gz[sl], y[sl], scale[g], shift[g], mean[g], invstd[g], act, out=gy[sl], params=params)
+                    params = (dgamma, dbeta)
                 if ctx.frozen:
                     scale = scale[0]    # (evaluation mode: the same running statistics for every group)
             gy_thin = gy

@@ -122,7 +122,7 @@ bn_bwd_reduce_kernel(const uint4 *__restrict__ gz, const uint4 *__restrict__ y, 
 __global__ void __launch_bounds__(1024)
 bn_bwd_finalize_kernel(const float *__restrict__ partial, int R, int C, const float *__restrict__ scale,
                        const float *__restrict__ mean, const float *__restrict__ invstd, float inv_n,
-                       float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ coef) {
+                       float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ coef, int acc) {
     __shared__ double fin[8][2][64];
     const int cg = blockIdx.x;
     {
@@ -144,8 +144,9 @@ bn_bwd_finalize_kernel(const float *__restrict__ partial, int R, int C, const fl
         double a = 0.0, b = 0.0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) { a += fin[k][0][cl]; b += fin[k][1][cl]; }
-        dbeta[c] = (float)a;
-        dgamma[c] = (float)b;
+        // (acc: the parameter gradients of an earlier sample group of the same layer are already there)
+        dbeta[c] = (acc ? dbeta[c] : 0.f) + (float)a;
+        dgamma[c] = (acc ? dgamma[c] : 0.f) + (float)b;
         if (scale) {
             const float scv = scale[c], isv = invstd[c], muv = mean[c];
             const float dg = (float)b * inv_n, db = (float)a * inv_n;
@@ -202,7 +203,8 @@ __global__ void __launch_bounds__(256)
 bn_bwd_finalize_apply_kernel(const float *__restrict__ partial, int R, int C, const float *__restrict__ scale,
                              const float *__restrict__ shift, const float *__restrict__ mean, const float *__restrict__ invstd,
                              float inv_n, float *__restrict__ dgamma, float *__restrict__ dbeta, const uint4 *__restrict__ gz,
-                             const uint4 *__restrict__ y, uint4 *__restrict__ gy, long npix, int act, int dt, long pix_per_block) {
+                             const uint4 *__restrict__ y, uint4 *__restrict__ gy, long npix, int act, int dt, long pix_per_block,
+                             int acc) {
     __shared__ double fin[2][2][64];
     __shared__ float co[3][64], ssc[64], ssh[64];
     const int cg = blockIdx.x, c0 = cg * 64;
@@ -233,7 +235,7 @@ bn_bwd_finalize_apply_kernel(const float *__restrict__ partial, int R, int C, co
         co[2][cl] = scv * (isv * muv * dg - db);
         ssc[cl] = scv;
         ssh[cl] = shift[c];
-        if (blockIdx.y == 0) { dbeta[c] = (float)a; dgamma[c] = (float)b; }
+        if (blockIdx.y == 0) { dbeta[c] = (acc ? dbeta[c] : 0.f) + (float)a; dgamma[c] = (acc ? dgamma[c] : 0.f) + (float)b; }
     }
     __syncthreads();
     const int oc = threadIdx.x & 7, prow = threadIdx.x >> 3;
@@ -403,7 +405,8 @@ extern "C" int ir2rgb_bn_bwd(const void *gz, const void *y, const float *scale, 
     if (R < 0) return R;
     if (dtype != IR2RGB_BF16 && dtype != IR2RGB_F16) return IR2RGB_ENOSUP;
     const bool frozen = act >= 0 && (act & 16);   // evaluation-mode BatchNorm: the mean / variance terms vanish
-    if (frozen) act &= 15;
+    const int acc = act >= 0 && (act & 32) ? 1 : 0;   // dgamma / dbeta += (a later sample group of a batched forward)
+    if (act >= 0) act &= 15;
     if (!gz || !y || !gy || !dgamma || !dbeta || !partial || act < 0 || act > 2) return IR2RGB_EINVAL;
     const int R0 = bn_bwd_ranges(npix, C);
     const long per = (npix + R0 - 1) / R0;
@@ -422,11 +425,11 @@ extern "C" int ir2rgb_bn_bwd(const void *gz, const void *y, const float *scale, 
         dim3 grid((unsigned)(C / 64), (unsigned)((npix + pp - 1) / pp));
         bn_bwd_finalize_apply_kernel<<<grid, 256, 0, s>>>(partial, R, C, scale, shift, mean, invstd,
                                                           frozen ? 0.f : 1.0f / (float)npix, dgamma, dbeta, (const uint4 *)gz,
-                                                          (const uint4 *)y, (uint4 *)gy, npix, act, dtype, pp);
+                                                          (const uint4 *)y, (uint4 *)gy, npix, act, dtype, pp, acc);
         return ir2rgb_launch_status();
     }
     bn_bwd_finalize_kernel<<<C / 64, 1024, 0, s>>>(partial, R, C, scale, mean, invstd, frozen ? 0.f : 1.0f / (float)npix, dgamma, dbeta,
-                                                  coef);
+                                                  coef, acc);
     long total8 = npix * (C / 8);
     bn_bwd_apply_kernel<<<stream_grid(total8, 256), 256, 0, s>>>((const uint4 *)gz, (const uint4 *)y, scale, shift, coef,
                                                                  (uint4 *)gy, total8, C / 8, act, dtype);
