@@ -38,6 +38,7 @@ struct WgradGeom {
     int nty, ntx, dy0, dx0; // tap (ty,tx): V coordinate = q*stride + (dy0+ty, dx0+tx)
     int ksplit, ksteps;     // K-steps (64 pixels each) in total and number of splits
     int use_atomics;
+    int tpb;                // taps per workgroup: 2 when Cb <= 64 (the two halves of the 128-column V tile hold two taps)
     FastDiv div_hw, div_w;  // exact division by Hq*Wq and by Wq
     unsigned u_bytes, v_bytes;  // extents of U and V (buffer resources, < 2^31)
 };
@@ -99,12 +100,15 @@ conv_wgrad_kernel(const uint16_t *__restrict__ U, const uint16_t *__restrict__ V
         const int nwg = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     }
+    // Thin layers (Cb <= 64: the full-resolution first / last layers, the 64-channel strided ones): the 128-column V tile
+    // holds TWO taps' 64 channels, so the U tile is streamed once per tap pair instead of once per tap and no half of the
+    // MFMA tile multiplies padding.  (One tap per workgroup re-read both operands for every tap: a 7x1 layer at
+    // 64 channels, 512x1024, moved 7 x 134 MB.)
+    const int ntaps = g.nty * g.ntx, ntg = (ntaps + g.tpb - 1) / g.tpb;
     const int tb = bid % ntb; bid /= ntb;
     const int ta = bid % nta; bid /= nta;
-    const int tap = bid % (g.nty * g.ntx);
-    const int split = bid / (g.nty * g.ntx);
-    const int ty = tap / g.ntx, tx = tap - ty * g.ntx;
-    const int dy = g.dy0 + ty, dx = g.dx0 + tx;
+    const int tapg = bid % ntg;
+    const int split = bid / ntg;
     const int a0 = ta * 128, b0 = tb * 128;
     const int per = (g.ksteps + g.ksplit - 1) / g.ksplit;
     const int kbeg = split * per, kend = min(g.ksteps, kbeg + per);
@@ -114,10 +118,15 @@ conv_wgrad_kernel(const uint16_t *__restrict__ U, const uint16_t *__restrict__ V
     const int slot = tid & 15, r0 = tid >> 4;                   // rows r0 + 16*i, i = 0..3
     const int f = (r0 & 3) | (((r0 >> 3) & 1) << 2);            // same for r0 + 16*i
     const int chunk = ((((slot >> 1) ^ f) << 1) | (slot & 1));  // source 16-B chunk held by this LDS slot
-    const bool a_ok = a0 + chunk * 8 < g.Ca, b_ok = b0 + chunk * 8 < g.Cb;
+    // this thread's V chunk: tap and channel offset (tpb == 2: chunks 0..7 = first tap of the pair, 8..15 = second)
+    const int vtap = g.tpb == 2 ? tapg * 2 + (chunk >> 3) : tapg;
+    const int vch = g.tpb == 2 ? (chunk & 7) * 8 : b0 + chunk * 8;
+    const int ty = vtap / g.ntx, tx = vtap - ty * g.ntx;
+    const int dy = g.dy0 + ty, dx = g.dx0 + tx;
+    const bool a_ok = a0 + chunk * 8 < g.Ca, b_ok = vch < g.Cb && vtap < ntaps;
     const rsrc_t ru = make_rsrc(U, g.u_bytes), rv = make_rsrc(V, g.v_bytes);
     const unsigned ubase = a_ok ? (unsigned)(a0 + chunk * 8) * 2u : WG_OOB;  // byte offset inside a pixel row
-    const unsigned vbase = b_ok ? (unsigned)(b0 + chunk * 8) * 2u : WG_OOB;
+    const unsigned vbase = b_ok ? (unsigned)vch * 2u : WG_OOB;
     const unsigned Q = (unsigned)g.N * g.Hq * g.Wq, HWq = (unsigned)g.Hq * g.Wq;
     const unsigned ca2 = (unsigned)g.Ca * 2u, cb2 = (unsigned)g.Cb * 2u;
     unsigned char *const wave_dst = smem + wave * 1024;  // + buf*STAGE + 4096*i (+16384 for V)
@@ -237,12 +246,15 @@ conv_wgrad_kernel(const uint16_t *__restrict__ U, const uint16_t *__restrict__ V
     }
 
     // ---------------- epilogue: D[split][tap][a][b] (fp32 slab of this K-split) ----------------
-    float *Dt = D + ((long)split * (g.nty * g.ntx) + tap) * g.Ca * g.Cb;
+    // (tpb == 2: the wave column wc is the tap of the pair, the channel is the column inside its 64)
+    const int tap = g.tpb == 2 ? tapg * 2 + wc : tapg;
+    if (tap >= ntaps) return;
+    float *Dt = D + ((long)split * ntaps + tap) * g.Ca * g.Cb;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-            const int b = b0 + wc * 64 + ni * 16 + l15;
+            const int b = g.tpb == 2 ? ni * 16 + l15 : b0 + wc * 64 + ni * 16 + l15;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int a = a0 + wr * 64 + mi * 16 + grp * 4 + r;
@@ -605,7 +617,12 @@ static int plan(const ir2rgb_conv_desc *d, WgradGeom *g) {
     g->ksteps = (int)((Q + 63) / 64);
     // K-split by a cost model: rounds of 512 resident workgroups (2 per CU) x (K-steps per split + pipeline
     // fill) against the extra slab traffic of the finish pass (split x elems x 8 bytes at ~4 TB/s).
-    const long tiles = (long)d->kh * d->kw * ((g->Ca + 127) / 128) * ((g->Cb + 127) / 128);
+    {
+        static int pairs = -1;
+        if (pairs < 0) { const char *e = getenv("IR2RGB_WGRAD_TAP_PAIRS"); pairs = e ? atoi(e) : 1; }
+        g->tpb = (pairs && g->Cb <= 64 && d->kh * d->kw > 1) ? 2 : 1;
+    }
+    const long tiles = (long)((d->kh * d->kw + g->tpb - 1) / g->tpb) * ((g->Ca + 127) / 128) * ((g->Cb + 127) / 128);
     const double elems = (double)d->kh * d->kw * g->Ca * g->Cb;
     int best = 1;
     double best_cost = 1e30;
@@ -684,7 +701,7 @@ static int wgrad_impl(const ir2rgb_conv_desc *d, const void *x, const void *gy, 
         return ir2rgb_launch_status();
     }
     const uint16_t *U = (const uint16_t *)(d->transposed ? x : gy), *V = (const uint16_t *)(d->transposed ? gy : x);
-    const unsigned grid = (unsigned)((long)g.ksplit * ntaps * ((g.Ca + 127) / 128) * ((g.Cb + 127) / 128));
+    const unsigned grid = (unsigned)((long)g.ksplit * ((ntaps + g.tpb - 1) / g.tpb) * ((g.Ca + 127) / 128) * ((g.Cb + 127) / 128));
     static int split = -1;
     if (split < 0) { const char *e = getenv("IR2RGB_WGRAD_SPLIT"); split = e ? atoi(e) : 1; }
     if (split) {

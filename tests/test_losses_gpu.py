@@ -265,13 +265,15 @@ def test_shared_discriminator_forward_changes_nothing():
     """netD on generated frames evaluated once (serving the D and the G loss through backward flags)
     against the reference's literal three forwards per compute_loss_D: same losses, bit-identical
     discriminator gradients, generator gradients equal up to the float atomics of the warp backward,
-    and BatchNorm running statistics advanced as by the literal sequence."""
+    and BatchNorm running statistics advanced as by the literal sequence.  With ``batched_D`` (the default: real |
+    generated | raw frames as one batch of sample groups) the convolutions tile and sum a three-sample batch, so the
+    same quantities agree to rounding instead of bit for bit."""
     from ir2rgb_amd import vid2vid as V
     dev = _dev()
     A, B = V.synthetic_sequence(9, 64, 128, 7, dev)
     runs = []
-    for shared in (True, False):
-        tr = V.Vid2VidTrainer(dev, seed=0, first_layer_gen_filters=64, gen_blocks=2, shared_fake_forward=shared)
+    for shared, batched in ((True, False), (False, False), (True, True)):
+        tr = V.Vid2VidTrainer(dev, seed=0, first_layer_gen_filters=64, gen_blocks=2, shared_fake_forward=shared, batched_D=batched)
         noop = lambda: None  # noqa: E731  keep the gradients, skip the updates
         tr.optimizer_G.step = tr.optimizer_D.step = noop
         for o in tr.optimizer_D_T:
@@ -292,3 +294,10 @@ def test_shared_discriminator_forward_changes_nothing():
         assert (a - b).norm().item() <= 1e-4 * b.norm().item() + 1e-12
     for a, b in zip(runs[0][3], runs[1][3]):
         assert torch.equal(a, b), "BatchNorm running statistics / counters differ"
+    # batched sample groups against the literal sequence
+    dev_l = max(abs(runs[2][0][k] - runs[1][0][k]) / max(abs(runs[1][0][k]), 1e-12) for k in runs[1][0])
+    dev_d = max(((a - b).norm() / b.norm().clamp_min(1e-20)).item() for a, b in zip(runs[2][2], runs[1][2]))
+    dev_g = max(((a - b).norm() / b.norm().clamp_min(1e-20)).item() for a, b in zip(runs[2][1], runs[1][1]))
+    dev_b = max(((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-20)).item() for a, b in zip(runs[2][3], runs[1][3]))
+    print("batched vs literal: losses %.2e, D gradients %.2e, G gradients %.2e, BatchNorm buffers %.2e" % (dev_l, dev_d, dev_g, dev_b))
+    assert dev_l <= 2e-3 and dev_d <= 3e-2 and dev_g <= 3e-2 and dev_b <= 1e-4, (dev_l, dev_d, dev_g, dev_b)
