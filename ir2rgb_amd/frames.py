@@ -30,9 +30,10 @@ class FrameHistory:
         self.keep = self.tD ** (self.t_scales - 1) * (self.tD - 1)     # frames the next push can still reach back to
         self.buf = None
         self.start = self.len = 0                                       # live frames: buf[:, start:start+len]
+        self.pushed = 0                                                 # frames pushed since the last reset
 
     def reset(self):
-        self.start = self.len = 0
+        self.start = self.len = self.pushed = 0
 
     def _reserve(self, B):
         b, n = B.shape[:2]
@@ -66,6 +67,7 @@ class FrameHistory:
 
     def push(self, B):
         n = B.shape[1]
+        self.pushed += n
         self._reserve(B)
         with torch.no_grad():
             self.buf[:, self.start + self.len:self.start + self.len + n].copy_(B)

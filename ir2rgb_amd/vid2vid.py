@@ -35,6 +35,7 @@ DEFAULTS = dict(  # options/base_options.py, options/train_options.py (SURVEY se
     no_vgg=True,         # VGG19 perceptual loss off: the pretrained weights cannot be downloaded here (False: ir2rgb_amd.vgg,
                          # randomly initialised unless a torchvision state_dict is loaded into trainer.vgg_loss.vgg)
     shared_fake_forward=True,   # one netD forward on generated frames serves the D and the G loss (autograd.backward_flags)
+    reuse_skipped_flows=True,   # reference flows of temporally skipped frame pairs seen in an earlier window are kept, not recomputed
     batched_D=True,      # (with shared_fake_forward) real | generated | raw frames go through a discriminator as ONE batch of sample groups
     fused_adam=True,     # one-launch HIP Adam (ir2rgb_amd.optim); False = torch.optim.Adam(foreach=True)
     fused_losses=True,   # grouped HIP loss kernels (ir2rgb_amd.losses); False = the same terms through torch ops
@@ -365,6 +366,7 @@ class Vid2VidTrainer:
     # ------------------------------------------------------------------ per-sequence state
     def reset_sequence(self):
         self.fake_B_prev = None          # pyramid of the last tG-1 generated frames
+        self._pair_flows = {}            # temporal scale -> [(push count, flow, conf)] of its newest pairs (reference_flows)
         # histories of the four streams the temporal discriminators sub-sample (train_vid2vid.py:45-52: real_B_all,
         # fake_B_all, flow_ref_all, conf_ref_all), each in one preallocated device buffer (ir2rgb_amd.frames)
         ts, tD = self.t_scales, self.tD
@@ -540,10 +542,22 @@ class Vid2VidTrainer:
         numerically (FlowNet2 is per-sample, frozen, eval mode)."""
         ts = self.t_scales
         rb_s = self.hist["real"].push(real_B)
+        pushed = self.hist["real"].pushed
         firsts, seconds, owners = [real_B.reshape((-1,) + tuple(real_B.shape[2:]))], [real_B_prev.reshape((-1,) + tuple(real_B.shape[2:]))], []
+        # Of the tD-1 frame pairs of a temporally skipped tuple (frames tD**s apart) only the newest is new: with one frame
+        # per window, pair k of this window is pair k+1 of the window tD**s pushes ago (same two real frames; FlowNet2 is
+        # frozen and per-sample), so its flow and confidence are kept instead of being recomputed (the reference recomputes
+        # them, discriminator.py:281-283; a third of its FlowNet2 work per window at t_scales 2 / tD 3).
+        reuse = self.opt["reuse_skipped_flows"] and real_B.shape[1] == 1 and self.tD == 3     # (tD 3: one older pair per tuple)
+        cached = {}
         for s in range(1, ts):
             if rb_s[s] is not None and rb_s[s].size(1) == self.tD:
                 a, b = rb_s[s][:, 1:], rb_s[s][:, :-1]
+                old = self._pair_flows.get(s, [])
+                hit = [e for e in old if e[0] == pushed - self.tD ** s] if reuse else []
+                if hit:
+                    cached[s] = hit[0]
+                    a, b = a[:, -1:], b[:, -1:]                          # only the newest pair goes through FlowNet2
                 firsts.append(a.reshape((-1,) + tuple(a.shape[2:])))
                 seconds.append(b.reshape((-1,) + tuple(b.shape[2:])))
                 owners.append((s, a.shape[0], a.shape[1]))
@@ -557,8 +571,14 @@ class Vid2VidTrainer:
         flow_ref, conf_ref = flow[:n0].view(b, t, 2, h, w), conf[:n0].view(b, t, 1, h, w)
         extra, off = {}, n0
         for s, bb, tt in owners:
-            extra[s] = (flow[off:off + bb * tt].view(bb, tt, 2, h, w), conf[off:off + bb * tt].view(bb, tt, 1, h, w))
+            fl, cf = flow[off:off + bb * tt].view(bb, tt, 2, h, w), conf[off:off + bb * tt].view(bb, tt, 1, h, w)
             off += bb * tt
+            if reuse:       # the newest pair's result serves the windows to come (tD - 2 more uses, tD**s pushes apart)
+                keep = [e for e in self._pair_flows.get(s, []) if e[0] > pushed - self.tD ** s * (self.tD - 2)]
+                self._pair_flows[s] = keep + [(pushed, fl[:, -1:], cf[:, -1:])]
+            if s in cached:                                              # (tD == 3: exactly one older pair)
+                fl, cf = torch.cat([cached[s][1], fl], 1), torch.cat([cached[s][2], cf], 1)
+            extra[s] = (fl, cf)
         return flow_ref, conf_ref, rb_s, extra
 
     def skipped_frames(self, rb_s, extra_flows, fake_B, flow_ref, conf_ref):

@@ -301,3 +301,18 @@ def test_shared_discriminator_forward_changes_nothing():
     dev_b = max(((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-20)).item() for a, b in zip(runs[2][3], runs[1][3]))
     print("batched vs literal: losses %.2e, D gradients %.2e, G gradients %.2e, BatchNorm buffers %.2e" % (dev_l, dev_d, dev_g, dev_b))
     assert dev_l <= 2e-3 and dev_d <= 3e-2 and dev_g <= 3e-2 and dev_b <= 1e-4, (dev_l, dev_d, dev_g, dev_b)
+
+
+def test_reused_skipped_pair_flows_change_nothing():
+    """reuse_skipped_flows: the reference flow / confidence of the older frame pair of a temporally skipped triplet is the
+    one FlowNet2 computed for the same two real frames three windows earlier (Vid2VidTrainer.reference_flows) -- every loss
+    of ten consecutive windows is bit-identical to recomputing it, as the reference does (discriminator.py:281-283)."""
+    from ir2rgb_amd import vid2vid as V
+    dev = _dev()
+    A, B = V.synthetic_sequence(12, 64, 128, 3, dev)
+    outs = []
+    for reuse in (True, False):
+        tr = V.Vid2VidTrainer(dev, seed=0, first_layer_gen_filters=64, gen_blocks=2, reuse_skipped_flows=reuse)
+        outs.append([{k: v.item() for k, v in tr.train_window(A[:, w:w + 3], B[:, w:w + 3]).items()} for w in range(10)])
+        assert "D_T1" in outs[-1][-1]
+    assert outs[0] == outs[1]
