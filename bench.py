@@ -182,7 +182,7 @@ def main():
         for a shape they do not cover.  (PMC counters cannot be collected inside this process.)"""
         try:
             with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_dominant_conv_traffic.json")) as f:
-                return json.load(f)["shapes"].get(",".join(str(int(v)) for v in key))
+                return json.load(f)["shapes"].get(",".join(v if isinstance(v, str) else str(int(v)) for v in key))
         except OSError:
             return None
 
