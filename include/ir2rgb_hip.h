@@ -300,6 +300,12 @@ int ir2rgb_bn_bwd(const void *gz, const void *y, const float *scale, const float
                   const float *invstd, void *gy, float *dgamma, float *dbeta, float *partial, long npix, int C,
                   int act, int dtype, void *stream);
 
+/* AvgPool2d(3, stride 2, padding 1, count_include_pad=False) on fp32 planes: the image pyramids of the multi-scale
+ * discriminators (reference networks.py:639, :658-666) and of the generator inputs (base_model.py:64-82).
+ * backward 0: x [planes][H][W] -> y [planes][Ho][Wo], Ho = (H-1)/2 + 1;  backward 1: x = the gradient
+ * [planes][Ho][Wo] -> y = the input gradient [planes][H][W]. */
+int ir2rgb_avgpool3s2(const float *x, float *y, long planes, int H, int W, int backward, void *stream);
+
 /* Gradient of a thin fp32 convolution output (the 1-channel PatchGAN logits, NLayerDiscriminator's last
  * layer, networks.py:676-677) prepared for the MFMA kernels: gz [N,Cout,H,W] fp32, Cout <= 8 ->
  * g64 [N,H,W,64] and g8 [N,H,W,8] NHWC half (channels >= Cout zero; data- / weight-gradient operands) and

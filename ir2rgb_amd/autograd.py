@@ -698,6 +698,38 @@ def warp_blend(raw, prev, flow, weight):
     return WarpBlendFn.apply(raw, prev, flow, weight)
 
 
+class AvgPool3s2Fn(Function):
+    """AvgPool2d(3, stride 2, padding 1, count_include_pad=False) of an fp32 [..., H, W] tensor (ir2rgb_avgpool3s2)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        h, w = x.shape[-2:]
+        ctx.shape = tuple(x.shape)
+        y = torch.empty(tuple(x.shape[:-2]) + ((h - 1) // 2 + 1, (w - 1) // 2 + 1), dtype=torch.float32, device=x.device)
+        with _lib.on_device(x):
+            rc = _lib.lib().ir2rgb_avgpool3s2(_p(x), _p(y), x.numel() // (h * w), h, w, 0, _lib.current_stream(x))
+        _lib.check(rc, "avgpool3s2")
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        gx = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        h, w = ctx.shape[-2:]
+        with _lib.on_device(g):
+            rc = _lib.lib().ir2rgb_avgpool3s2(_p(g), _p(gx), gx.numel() // (h * w), h, w, 1, _lib.current_stream(g))
+        _lib.check(rc, "avgpool3s2 backward")
+        return gx
+
+
+def avg_pool3s2(x):
+    """The pyramids' down-sampling step; torch's operator for anything but fp32 GPU tensors."""
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() >= 2:
+        return AvgPool3s2Fn.apply(x)
+    return torch.nn.functional.avg_pool2d(x, 3, stride=2, padding=1, count_include_pad=False)
+
+
 class AddFn(Function):
     """a + b on channels_last half tensors (HIP), gradient passed to both."""
 

@@ -525,3 +525,60 @@ extern "C" int ir2rgb_nchw_f32_to_nhwc_half_slice(const float *in, void *out, in
     return ir2rgb_launch_status();
 }
 
+
+// ------------------------------------------------------------------------------------------
+// AvgPool2d(3, stride 2, padding 1, count_include_pad=False) on fp32 planes -- the image pyramids of the multi-scale
+// discriminators (reference networks.py:639, :658-666) and of the generator inputs (base_model.py:64-82), forward and
+// backward.  (torch's kernels take 38 / 102 us per call on three 6-channel 512x1024 frames; the tensors are 10 us of HBM time.)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+avgpool3s2_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, int H, int W, int Ho, int Wo, long total) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % Wo);
+        const long r = i / Wo;
+        const int oy = (int)(r % Ho);
+        const long p = r / Ho;
+        const int y0 = max(2 * oy - 1, 0), y1 = min(2 * oy + 1, H - 1), x0 = max(2 * ox - 1, 0), x1 = min(2 * ox + 1, W - 1);
+        const float *src = x + p * (long)H * W;
+        float s = 0.f;
+        for (int yy = y0; yy <= y1; ++yy)
+            for (int xx = x0; xx <= x1; ++xx) s += src[(long)yy * W + xx];
+        y[i] = s / (float)((y1 - y0 + 1) * (x1 - x0 + 1));
+    }
+}
+
+__global__ void __launch_bounds__(256)
+avgpool3s2_bwd_kernel(const float *__restrict__ gy, float *__restrict__ gx, int H, int W, int Ho, int Wo, long total) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % W);
+        const long r = i / W;
+        const int yy = (int)(r % H);
+        const long p = r / H;
+        // outputs whose 3x3 window (rows 2oy-1 .. 2oy+1) contains this pixel: oy in [ceil((yy-1)/2), floor((yy+1)/2)]
+        const int oy0 = yy >> 1, oy1 = min((yy + 1) >> 1, Ho - 1), ox0 = xx >> 1, ox1 = min((xx + 1) >> 1, Wo - 1);
+        const float *src = gy + p * (long)Ho * Wo;
+        float s = 0.f;
+        for (int oy = oy0; oy <= oy1; ++oy) {
+            const int ny = min(2 * oy + 1, H - 1) - max(2 * oy - 1, 0) + 1;
+            for (int ox = ox0; ox <= ox1; ++ox) {
+                const int nx = min(2 * ox + 1, W - 1) - max(2 * ox - 1, 0) + 1;
+                s += src[(long)oy * Wo + ox] / (float)(ny * nx);
+            }
+        }
+        gx[i] = s;
+    }
+}
+
+extern "C" int ir2rgb_avgpool3s2(const float *x, float *y, long planes, int H, int W, int backward, void *stream) {
+    if (!x || !y || planes < 0 || H < 1 || W < 1) return IR2RGB_EINVAL;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    hipStream_t s = as_stream(stream);
+    if (!backward) {      // x [planes][H][W] -> y [planes][Ho][Wo]
+        const long total = planes * Ho * Wo;
+        if (total) avgpool3s2_fwd_kernel<<<stream_grid(total, 256), 256, 0, s>>>(x, y, H, W, Ho, Wo, total);
+    } else {              // x = gradient [planes][Ho][Wo] -> y = input gradient [planes][H][W]
+        const long total = planes * H * W;
+        if (total) avgpool3s2_bwd_kernel<<<stream_grid(total, 256), 256, 0, s>>>(x, y, H, W, Ho, Wo, total);
+    }
+    return ir2rgb_launch_status();
+}

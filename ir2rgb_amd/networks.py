@@ -508,7 +508,7 @@ class MultiScaleDiscriminator(nn.Module):
                                  group_order)
             result.append(outs if self.getIntermFeat else [outs[-1]])
             if i != self.num_D - 1:
-                x = self.downsample(x)
+                x = A.avg_pool3s2(x)       # = self.downsample (networks.py:639), forward and backward in one HIP kernel each
         L.flush_bn_counters()
         return result
 

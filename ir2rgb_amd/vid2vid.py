@@ -50,8 +50,8 @@ def avg_pool_pyramid(t, n_scales):
     out = [t]
     for _ in range(1, n_scales):
         b, tt, c, h, w = out[-1].shape
-        d = F.avg_pool2d(out[-1].reshape(-1, h, w).unsqueeze(1), 3, stride=2, padding=1, count_include_pad=False)
-        out.append(d.view(b, tt, c, h // 2, w // 2))
+        d = autograd.avg_pool3s2(out[-1].reshape(-1, h, w).unsqueeze(1))
+        out.append(d.view(b, tt, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1))
     return out
 
 

@@ -404,3 +404,21 @@ def test_discriminator_inactive_sample_groups(dev):
         grads.append([x.grad.clone() for x in xs[:2]])
     for a, b in zip(*grads):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("shape", [(3, 6, 64, 96), (2, 1, 33, 47), (1, 2, 3, 5, 1, 7)])
+def test_avg_pool3s2_matches_torch(dev, shape):
+    """ir2rgb_avgpool3s2 (the pyramids' AvgPool2d(3, 2, 1, count_include_pad=False), networks.py:639 / base_model.py:64-82)
+    against torch's operator, forward and backward, odd sizes and a one-pixel-high plane included."""
+    from ir2rgb_amd import autograd as A
+    g = torch.Generator().manual_seed(sum(shape))
+    x1 = torch.randn(*shape, generator=g).to(dev).requires_grad_(True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    y1 = A.avg_pool3s2(x1)
+    y2 = torch.nn.functional.avg_pool2d(x2.reshape((-1, 1) + tuple(shape[-2:])), 3, stride=2, padding=1, count_include_pad=False)
+    y2 = y2.reshape(y1.shape)
+    torch.testing.assert_close(y1, y2, rtol=1e-6, atol=1e-6)
+    go = torch.randn(y1.shape, generator=g).to(dev)
+    y1.backward(go)
+    y2.backward(go)
+    torch.testing.assert_close(x1.grad, x2.grad, rtol=1e-6, atol=1e-6)
