@@ -36,6 +36,7 @@ DEFAULTS = dict(  # options/base_options.py, options/train_options.py (SURVEY se
                          # randomly initialised unless a torchvision state_dict is loaded into trainer.vgg_loss.vgg)
     shared_fake_forward=True,   # one netD forward on generated frames serves the D and the G loss (autograd.backward_flags)
     reuse_skipped_flows=True,   # reference flows of temporally skipped frame pairs seen in an earlier window are kept, not recomputed
+    allreduce_chunk_elems=32 * 1024 * 1024,   # fp32 elements per gradient all-reduce (128 MB)
     batched_D=True,      # (with shared_fake_forward) real | generated | raw frames go through a discriminator as ONE batch of sample groups
     fused_adam=True,     # one-launch HIP Adam (ir2rgb_amd.optim); False = torch.optim.Adam(foreach=True)
     fused_losses=True,   # grouped HIP loss kernels (ir2rgb_amd.losses); False = the same terms through torch ops
@@ -240,7 +241,11 @@ class FlatGrads:
     write their weight gradients straight into their slices (ir2rgb_amd.autograd.GRAD_SINKS), so 99.9 % of the
     buffer is in place when the pass ends; the rest (biases, BatchNorm parameters, first / thin / padded layers) is
     gathered by one multi-tensor copy, as everything is when ``direct`` is off (the discriminators: several
-    contributions per parameter and pass, summed by the autograd engine before they are adopted)."""
+    contributions per parameter and pass, summed by the autograd engine before they are adopted).  The in-place
+    weights sit at the front of the buffer in parameter order, cut into chunks; a chunk goes onto the wire from the
+    autograd hook of the parameter that completes it, i.e. WHILE the backward pass is still running (the generators'
+    1.4 GB of residual-block gradients are produced over the last ~5 ms of their pass: the all-reduce then ends about
+    when the pass does instead of starting there); ``all_reduce_async`` sends what is left."""
 
     def __init__(self, params, chunk_elems=32 * 1024 * 1024, world=1, direct=False):
         self.params = [p for p in params if p.requires_grad]
@@ -248,23 +253,76 @@ class FlatGrads:
         n = sum(pad4(p.numel()) for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.views, off = [], 0
-        for p in self.params:
-            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+        self.direct = bool(direct and world > 1)
+        # layout: with ``direct`` the convolution weights (written in place by their weight-gradient kernels) come first,
+        # in parameter order, so that whole chunks of the buffer are complete -- and can be all-reduced -- while the
+        # backward pass is still running; biases / BatchNorm parameters (gathered by one copy when the pass ends) follow
+        is_sink = [self.direct and p.dim() == 4 for p in self.params]
+        order = [i for i, s in enumerate(is_sink) if s] + [i for i, s in enumerate(is_sink) if not s]
+        self.views, off = [None] * len(self.params), 0
+        starts = {}
+        for i in order:
+            p = self.params[i]
+            starts[i] = off
+            self.views[i] = self.flat[off:off + p.numel()].view_as(p)
             off += pad4(p.numel())
         self.chunk = chunk_elems
         self.handles = []
         self.scale_after = None
-        if direct and world > 1:
-            for p, v in zip(self.params, self.views):
-                if p.dim() == 4:
-                    autograd.GRAD_SINKS[p] = v
+        # early chunks: [lo, hi) ranges of the sink region, each a list of parameter indices; a chunk is all-reduced from
+        # the autograd hook of the parameter whose gradient completes it (all_reduce_async picks up what is left)
+        self.chunks, self._fired, self._pending, self._issued, self._world = [], set(), [], [], world
+        if self.direct:
+            cur, lo = [], 0
+            sink_ids = [i for i in order if is_sink[i]]
+            for k, i in enumerate(sink_ids):
+                cur.append(i)
+                hi = starts[i] + pad4(self.params[i].numel())
+                if hi - lo >= chunk_elems or k == len(sink_ids) - 1:
+                    self.chunks.append((lo, hi, tuple(cur)))
+                    cur, lo = [], hi
+            self.sink_end = self.chunks[-1][1] if self.chunks else 0
+            chunk_of = {i: c for c, (_, _, ids) in enumerate(self.chunks) for i in ids}
+            for i in sink_ids:
+                p = self.params[i]
+                autograd.GRAD_SINKS[p] = self.views[i]
+                p.register_post_accumulate_grad_hook(self._make_hook(i, chunk_of[i]))
+        else:
+            self.sink_end = 0
+
+    def _make_hook(self, i, c):
+        def hook(p):
+            if not self._pending or i in self._fired:
+                return
+            self._fired.add(i)
+            if p.grad is None or p.grad.data_ptr() != self.views[i].data_ptr():
+                self._pending[c] = -1                      # this gradient is not in place: the chunk waits for the gather
+                return
+            if self._pending[c] > 0:
+                self._pending[c] -= 1
+                if self._pending[c] == 0:
+                    lo, hi, _ = self.chunks[c]
+                    self._reduce(lo, hi)
+                    self._issued[c] = True
+        return hook
+
+    def _reduce(self, lo, hi):
+        avg = dist.get_backend() == "nccl"     # RCCL averages in the collective; gloo (CPU tests) has no AVG
+        self.scale_after = None if avg else 1.0 / self._world
+        for i in range(lo, hi, self.chunk):
+            self.handles.append(dist.all_reduce(self.flat[i:min(i + self.chunk, hi)], op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM,
+                                                async_op=True))
 
     def zero(self):
         for p in self.params:
             p.grad = None
+        if self.direct:      # arm the early chunks for the backward pass that follows
+            self._fired = set()
+            self._pending = [len(ids) for _, _, ids in self.chunks]
+            self._issued = [False] * len(self.chunks)
 
     def all_reduce_async(self, world):
+        self._world = world
         src, dst, missing = [], [], []
         for p, v in zip(self.params, self.views):
             if p.grad is None:
@@ -276,17 +334,33 @@ class FlatGrads:
                 p.grad = v
             elif world > 1:
                 p.grad = v              # written in place by its convolution (GRAD_SINKS)
+        issued, self._pending = self._issued, []           # (disarm the hooks)
         if missing:
+            if any(issued):
+                lo_hi = [(lo, hi) for (lo, hi, _), done in zip(self.chunks, issued) if done]
+                base = self.flat.data_ptr()
+                for v in missing:       # a parameter without gradient inside a chunk that is already on the wire cannot happen:
+                    o = (v.data_ptr() - base) // 4          # its chunk never completes
+                    assert not any(lo <= o < hi for lo, hi in lo_hi), "FlatGrads: early chunk reduced before it was complete"
             torch._foreach_zero_(missing)      # one multi-tensor launch instead of one fill per parameter
         if world <= 1:
             return
         if src:
             torch._foreach_copy_(dst, src)
-        avg = dist.get_backend() == "nccl"     # RCCL averages in the collective; gloo (CPU tests) has no AVG
-        self.scale_after = None if avg else 1.0 / world
-        for i in range(0, self.flat.numel(), self.chunk):
-            self.handles.append(dist.all_reduce(self.flat[i:i + self.chunk], op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM,
-                                                async_op=True))
+        # what the hooks have not sent: unfinished chunks of the sink region (merged into runs), then the gathered tail
+        run = None
+        for (lo, hi, _), done in zip(self.chunks, issued or [False] * len(self.chunks)):
+            if done:
+                if run is not None:
+                    self._reduce(*run)
+                    run = None
+            else:
+                run = (lo, hi) if run is None else (run[0], hi)
+        tail_lo = self.sink_end
+        if run is not None:
+            tail_lo = run[0]
+        self._reduce(tail_lo, self.flat.numel())
+        self._issued = []
 
     def wait(self):
         for h in self.handles:
@@ -339,7 +413,7 @@ class Vid2VidTrainer:
         # and the packed MFMA weights (ir2rgb_amd.layers.packed_weight) are refreshed on a version change
         adam = dict(lr=o["lr"], betas=(o["beta1"], 0.999), foreach=True)
         # (generators: one use per parameter and pass when one frame is generated per window, see generate())
-        self.grads_G = FlatGrads(g_params, world=world_size, direct=o["max_frames_per_gpu"] == 1)
+        self.grads_G = FlatGrads(g_params, chunk_elems=o["allreduce_chunk_elems"], world=world_size, direct=o["max_frames_per_gpu"] == 1)
         self.grads_D = FlatGrads(self.netD.parameters())
         self.grads_DT = [FlatGrads(d.parameters()) for d in self.netD_T]
         if o["fused_adam"]:

@@ -33,7 +33,10 @@ def _worker(rank, world, port, outdir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from ir2rgb_amd import vid2vid as V
     dev = torch.device("cuda:0")
-    kw = dict(seed=0, first_layer_gen_filters=64, compute_dtype=torch.float16, build_flow_net=False)
+    # (small chunks: the generators' gradient buffer then leaves in many pieces, most of them from the autograd hooks
+    # while the backward pass is still running)
+    kw = dict(seed=0, first_layer_gen_filters=64, compute_dtype=torch.float16, build_flow_net=False,
+              allreduce_chunk_elems=1 << 20)
     tr, twin = V.Vid2VidTrainer(dev, world_size=world, **kw), V.Vid2VidTrainer(dev, world_size=1, **kw)
     tr.flow_net = twin.flow_net = stub_flow_and_conf
     copied = []
@@ -41,7 +44,11 @@ def _worker(rank, world, port, outdir):
     torch._foreach_copy_ = lambda dst, src, *a, **k: (copied.append(sum(t.numel() for t in dst)), orig_copy(dst, src, *a, **k))[1]
     A, B = V.synthetic_sequence(3, 64, 128, 100 + rank, dev)
     twin.train_window(A, B)                                  # local gradients (Adam does not touch .grad)
+    early = []
+    orig_reduce = V.FlatGrads._reduce
+    V.FlatGrads._reduce = lambda self, lo, hi: (early.append((bool(self._pending), hi - lo)), orig_reduce(self, lo, hi))[1]
     tr.train_window(A, B)
+    V.FlatGrads._reduce = orig_reduce
     torch._foreach_copy_ = orig_copy
     res = {}
     for name, mods_a, mods_b in (("G", tr.netG, twin.netG), ("D", [tr.netD], [twin.netD])):
@@ -57,6 +64,7 @@ def _worker(rank, world, port, outdir):
         res[name + "_params_equal"] = bool(torch.equal(gathered[0], gathered[1]))
         res[name + "_local_differs"] = ((both[0] - both[1]).norm() / mean.norm()).item()
     n_g = sum(p.numel() for m in tr.netG for p in m.parameters())
+    res["early_fraction_of_G"] = sum(n for armed, n in early if armed) / n_g   # sent from hooks, during the backward pass
     res["copied_fraction_of_G"] = copied[0] / n_g if copied else 0.0     # the first gather of the window is the generators'
     torch.save(res, os.path.join(outdir, f"rank{rank}.pt"))
     dist.barrier()
@@ -75,3 +83,4 @@ def test_two_rank_window_on_one_gpu(tmp_path):
         assert res["G_params_equal"] and res["D_params_equal"], res   # ranks stay identical after the step
         assert res["G_local_differs"] > 1e-2                          # (the two ranks really saw different windows)
         assert res["copied_fraction_of_G"] < 0.02, res                # the generator's weight gradients were written in place
+        assert res["early_fraction_of_G"] > 0.8, res                  # ... and left while the backward pass was running
