@@ -181,7 +181,10 @@ class FlowNet(torch.nn.Module):
                 a, b = im1.clone(), im2.clone()
                 torch.cuda.synchronize(im1.device)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # (with a process group alive its watchdog thread polls events meanwhile: only this thread's calls are
+                # subject to the capture rules then)
+                mode = "thread_local" if dist.is_available() and dist.is_initialized() else "global"
+                with torch.cuda.graph(g, capture_error_mode=mode):
                     out = self._flow_and_conf_eager(a, b)
                 ent = self._graphs[key] = (g, a, b, out)
             except Exception as e:  # noqa: BLE001  capture is an optimisation, never a requirement
@@ -396,11 +399,14 @@ class Vid2VidTrainer:
         for m in self.netG + [self.netD] + self.netD_T:
             m.to(device).train()
             m.compute_dtype = o["compute_dtype"]
-        # HIP-graph replay of FlowNet2 only in the single-process case: it saves host time, not GPU time, and
-        # graph capture next to RCCL's watchdog thread cannot be exercised on the one-GPU development box
+        # FlowNet2 is replayed from a HIP graph in every configuration (a capture next to a process group runs in
+        # thread-local mode, FlowNet.compute_flow_and_conf); the SECOND STREAM for the replay is a single-process feature:
+        # with two ranks on one GPU over gloo (bench.py rehearsal) the replay on the second stream next to the collectives
+        # ran 7.6 s per window against 0.43 s on the main stream -- a gloo artefact in all likelihood, but RCCL cannot be run
+        # on the one-GPU development box (IR2RGB_FLOW_STREAM_DP=1 enables the second stream for data-parallel ranks)
         self.flow_net = None
         if o["build_flow_net"]:
-            self.flow_net = FlowNet(o["flownet_dtype"], use_graph=None if world_size == 1 else False).to(device)
+            self.flow_net = FlowNet(o["flownet_dtype"], use_graph=None).to(device)
         self._side_wgrad = None          # set per window in generate(): safe only when n_load == 1
         self.vgg_loss = None
         if not o["no_vgg"]:
@@ -430,6 +436,8 @@ class Vid2VidTrainer:
         """The side stream FlowNet2 runs on (None: same stream as everything else; IR2RGB_FLOW_STREAM=0 or CPU tensors)."""
         import os
         if not t.is_cuda or os.environ.get("IR2RGB_FLOW_STREAM", "1") == "0":
+            return None
+        if self.world > 1 and os.environ.get("IR2RGB_FLOW_STREAM_DP", "0") != "1":
             return None
         if not isinstance(self.flow_net, FlowNet):
             return None
