@@ -57,7 +57,7 @@ struct P3Geom {
     int stats_row0, nty, ntx;         // pixel tiles per image: nty x ntx
     int cout_major, kchunks;
     unsigned x_bytes, w_bytes;
-    int dbg;   // ablation switches for timing experiments (IR2RGB_CONV3X3P_DBG; results are garbage): 1 = no staging after the prologue, 2 = no fragment reads
+    int dbg;   // ablation switches for timing experiments, honoured only by -DIR2RGB_ABLATION builds (results are garbage): 1 = no staging after the prologue, 2 = no fragment reads
 };
 
 __device__ __forceinline__ int p3_reflect(int v, int n) {
@@ -656,7 +656,9 @@ int conv3x3p_plan(const ir2rgb_conv_desc *d, P3Geom *g, int *npt_out, bool allow
     g->kchunks = d->Cin / 64;
     g->x_bytes = (unsigned)xb; g->w_bytes = (unsigned)wb;
     g->cout_major = wb > (long)d->N * d->Hin * d->Win * d->Cin * 2 ? 1 : 0;
+#ifdef IR2RGB_ABLATION   // timing experiments only (tools/conv_ablate.py; build with -DIR2RGB_ABLATION): results are garbage
     { static int dbg = -1; if (dbg < 0) { const char *e = getenv("IR2RGB_CONV3X3P_DBG"); dbg = e ? atoi(e) : 0; } g->dbg = dbg; }
+#endif
     if (d->pad_mode == 1 && (d->pad_h >= d->Hin || d->pad_w >= d->Win)) return 0;
     *npt_out = d->N * ((d->Hout + 1) / 2) * g->ntx;    // rows of the statistics buffer: 2-row tiles in every variant
     return variant;

@@ -1,4 +1,4 @@
-"""Timing ablations of the patch-staged 3x3 kernel (IR2RGB_CONV3X3P_DBG: 1 = no staging after the prologue, 2 = no fragment
+"""Timing ablations of the patch-staged 3x3 kernel (library built with -DIR2RGB_ABLATION; IR2RGB_CONV3X3P_DBG: 1 = no staging after the prologue, 2 = no fragment
 reads, 3 = neither; results are garbage, only the time means something).  Shapes: 1024@32x64 (split form) and 1024@64x128."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
