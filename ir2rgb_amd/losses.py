@@ -60,6 +60,16 @@ def _build_items(terms, tensors, grads):
     return arr
 
 
+# Gradient destinations: (data_ptr, shape, dtype) of a loss input -> the tensor its gradient is to be written into
+# (vid2vid.split_groups registers the pieces of a batched discriminator output with their slices of ONE gradient buffer,
+# so the pieces' gradients need no gather copy).  The destination itself is returned as the gradient.
+GRAD_DST = {}
+
+
+def _dst_key(t):
+    return (t.data_ptr(), tuple(t.shape), t.dtype)
+
+
 class _FusedLossFn(Function):
     @staticmethod
     def forward(ctx, terms, nslots, dt, *tensors):
@@ -85,7 +95,14 @@ class _FusedLossFn(Function):
         for t in terms:
             pos.append(ti)
             ti += 1 + (1 if t[0] == "l1" else 0) + ((1 if t[1] else 0) + 1 if t[0] == "ml1" else 0)
-        grads = [torch.empty_like(tensors[p]) if ctx.needs_input_grad[3 + p] else None for p in pos]
+        grads = []
+        for p in pos:
+            g = None
+            if ctx.needs_input_grad[3 + p]:
+                g = GRAD_DST.get(_dst_key(tensors[p])) if GRAD_DST else None
+                if g is None or g.stride() != tensors[p].stride():
+                    g = torch.empty_like(tensors[p])
+            grads.append(g)
         if any(g is not None for g in grads):
             gout = gout.contiguous().float()
             arr = _build_items(terms, tensors, grads)

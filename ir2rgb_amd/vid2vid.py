@@ -91,36 +91,45 @@ def gan_loss(pred, real):
 
 
 class _SplitGroupsFn(torch.autograd.Function):
-    """t [G * n, ...] -> G views [n, ...]; backward: the pieces' gradients written into ONE buffer of t's layout, zeros
-    where a piece received none (autograd's own slicing would allocate and fill a full-size zero tensor per piece and add
-    them up; materialised zero gradients would also arrive NCHW-contiguous and drag the whole buffer out of NHWC)."""
+    """t [G * n, ...] -> G views [n, ...]; backward: the pieces' gradients in ONE buffer of t's layout (autograd's own
+    slicing would allocate and fill a full-size zero tensor per piece and add them up; materialised zero gradients would
+    also arrive NCHW-contiguous and drag the whole buffer out of NHWC).  The buffer exists from the forward on and its
+    slices are registered as the gradient destinations of the pieces (losses.GRAD_DST): a fused loss kernel that
+    differentiates a piece writes straight into it, anything else is copied in; a piece without gradient is zero-filled
+    unless its sample group is inactive in this pass (``owner._ir2rgb_active``, autograd.backward_flags: nobody reads it)."""
 
     @staticmethod
-    def forward(ctx, t, G):
+    def forward(ctx, t, G, owner):
+        from . import losses
         n = t.shape[0] // G
         ctx.set_materialize_grads(False)
-        ctx.G, ctx.n = G, n
-        ctx.meta = (tuple(t.shape), t.dtype, t.device,
-                    torch.channels_last if t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) else torch.contiguous_format)
-        return tuple(t[g * n:(g + 1) * n] for g in range(G))
+        ctx.G, ctx.n, ctx.owner = G, n, owner
+        fmt = torch.channels_last if t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) else torch.contiguous_format
+        ctx.buf = torch.empty(tuple(t.shape), dtype=t.dtype, device=t.device, memory_format=fmt)
+        pieces = tuple(t[g * n:(g + 1) * n] for g in range(G))
+        for g, piece in enumerate(pieces):
+            losses.GRAD_DST[losses._dst_key(piece)] = ctx.buf[g * n:(g + 1) * n]
+        return pieces
 
     @staticmethod
     def backward(ctx, *grads):
         if all(g is None for g in grads):
-            return None, None
-        shape, dtype, device, fmt = ctx.meta
-        out = torch.empty(shape, dtype=dtype, device=device, memory_format=fmt)
-        n = ctx.n
+            return None, None, None
+        out, n = ctx.buf, ctx.n
+        active = getattr(ctx.owner, "_ir2rgb_active", None) if ctx.owner is not None else None
         for i, g in enumerate(grads):
+            dst = out[i * n:(i + 1) * n]
             if g is None:
-                out[i * n:(i + 1) * n].zero_()
-            else:
-                out[i * n:(i + 1) * n].copy_(g)
-        return out, None
+                if active is None or i < active:
+                    dst.zero_()
+            elif g.data_ptr() != dst.data_ptr():
+                dst.copy_(g)
+        return out, None, None
 
 
-def split_groups(t, G):
-    return _SplitGroupsFn.apply(t, G)
+def split_groups(t, G, owner=None):
+    """``owner``: a convolution module of the network that produced ``t`` (carries the pass's active-group flag)."""
+    return _SplitGroupsFn.apply(t, G, owner)
 
 
 @contextlib.contextmanager
@@ -554,10 +563,11 @@ class Vid2VidTrainer:
         G = len(inputs)
         with layers.repeated_forward(tuple(repeats)):
             out = netD(torch.cat(inputs, 0), sample_groups=G, group_order=order)
+        owner = next(m for m in netD.modules() if isinstance(m, torch.nn.Conv2d))
         preds = [[[] for _ in out] for _ in range(G)]
         for i, scale in enumerate(out):
             for t in scale:
-                for g, piece in enumerate(split_groups(t, G)):
+                for g, piece in enumerate(split_groups(t, G, owner)):
                     preds[g][i].append(piece)
         return preds
 
@@ -734,6 +744,8 @@ class Vid2VidTrainer:
         ``D_T{s}`` and every term under the reference's names (``G_GAN`` ... ``W``; temporal ones with the scale
         appended, ``G_T_GAN0`` ...).  ``self.last_outputs`` keeps (fake_B, fake_B_raw, flow, weight), detached."""
         fake_prev_last = self.fake_B_prev
+        from . import losses as _losses
+        _losses.GRAD_DST.clear()            # (gradient destinations of the previous window's discriminator outputs)
         # The reference flows depend on real frames only (train_vid2vid.py:62-65 computes them after the generator, from
         # real_Bp = input_B[:, tG-2:]): FlowNet2 -- frozen, no autograd, replayed from a HIP graph from its third call at a
         # shape on -- runs on a second HIP stream BESIDE the generator forward and is joined before the losses that read
