@@ -300,6 +300,10 @@ int ir2rgb_bn_bwd(const void *gz, const void *y, const float *scale, const float
                   const float *invstd, void *gy, float *dgamma, float *dbeta, float *partial, long npix, int C,
                   int act, int dtype, void *stream);
 
+/* dst[i] = idx[i] >= 0 ? src[idx[i]] : 0 (fp32; n elements): rearranged copies of a weight tensor (x-im2col layout of
+ * the first layers, zero-padded widths) from a precomputed index map, refreshed after every optimizer step. */
+int ir2rgb_gather_f32(const float *src, const int *idx, float *dst, long n, void *stream);
+
 /* AvgPool2d(3, stride 2, padding 1, count_include_pad=False) on fp32 planes: the image pyramids of the multi-scale
  * discriminators (reference networks.py:639, :658-666) and of the generator inputs (base_model.py:64-82).
  * backward 0: x [planes][H][W] -> y [planes][Ho][Wo], Ho = (H-1)/2 + 1;  backward 1: x = the gradient

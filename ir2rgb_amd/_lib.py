@@ -48,6 +48,7 @@ PROTOTYPES = {
     "ir2rgb_version": (ctypes.c_char_p, []),
     "ir2rgb_correlation_out_shape": (c_int, [c_int] * 8 + [_pint] * 3),
     "ir2rgb_correlation_fwd": (c_int, [P, P, P] + [c_int] * 9 + [P]),
+    "ir2rgb_gather_f32": (c_int, [P, P, P, c_long, P]),
     "ir2rgb_avgpool3s2": (c_int, [P, P, c_long, c_int, c_int, c_int, P]),
     "ir2rgb_correlation_nhwc_half": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_float] + [c_int] * 5 + [P]),
     "ir2rgb_correlation_bwd": (c_int, [P, P, P, P, P] + [c_int] * 9 + [P]),

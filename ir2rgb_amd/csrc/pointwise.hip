@@ -582,3 +582,20 @@ extern "C" int ir2rgb_avgpool3s2(const float *x, float *y, long planes, int H, i
     }
     return ir2rgb_launch_status();
 }
+
+// dst[i] = idx[i] >= 0 ? src[idx[i]] : 0 -- a rearranged fp32 copy of a weight (x-im2col of the first layers, zero-padded
+// widths, the separable heads' row split) as ONE launch from a precomputed index map (ir2rgb_amd.layers.packed_weight),
+// instead of the chain of torch permute / reshape / pad / cat launches it replaces after every optimizer step.
+__global__ void __launch_bounds__(256)
+gather_f32_kernel(const float *__restrict__ src, const int *__restrict__ idx, float *__restrict__ dst, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int j = idx[i];
+        dst[i] = j >= 0 ? src[j] : 0.f;
+    }
+}
+
+extern "C" int ir2rgb_gather_f32(const float *src, const int *idx, float *dst, long n, void *stream) {
+    if (n < 0 || (n > 0 && (!src || !idx || !dst))) return IR2RGB_EINVAL;
+    if (n) gather_f32_kernel<<<stream_grid(n, 256), 256, 0, as_stream(stream)>>>(src, idx, dst, n);
+    return ir2rgb_launch_status();
+}

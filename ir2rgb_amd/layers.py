@@ -36,32 +36,70 @@ def _require_gpu(t, what):
 # ---------------------------------------------------------------------------------------------
 # packed-weight cache
 # ---------------------------------------------------------------------------------------------
+def _gather(src, idx, dst):
+    with _lib.on_device(src):
+        rc = _lib.lib().ir2rgb_gather_f32(_p(src), _p(idx), _p(dst), dst.numel(), _lib.current_stream(src))
+    _lib.check(rc, "gather_f32")
+    return dst
+
+
+def _gather_plan(mod, tag, weight, src):
+    """Index map of the rearrangement ``weight`` (a pure data movement: permute / reshape / zero-pad / cat with zeros) of
+    ``mod.weight``, found by running it once on a tensor of 1-based element numbers (0 = a zero the rearrangement put
+    there); cached per (module, tag).  None when ``weight`` is not such a map (checked once against its own result)."""
+    plans = mod.__dict__.setdefault("_ir2rgb_gather", {})
+    key = (src.data_ptr(), tuple(src.shape))
+    hit = plans.get(tag)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    plan = None
+    n = src.numel()
+    if n < (1 << 24):                # element numbers stay exact in fp32
+        with torch.no_grad():
+            r = weight(torch.arange(1, n + 1, dtype=torch.float32, device=src.device).view_as(src)).float().contiguous()
+            idx = (r.round().to(torch.int32) - 1).contiguous()
+            wbuf = torch.empty(r.shape, dtype=torch.float32, device=src.device)
+            ref = weight(src.detach()).float().contiguous()
+            if ref.shape == wbuf.shape and torch.equal(_gather(src.detach().contiguous().view(-1), idx, wbuf), ref):
+                plan = (idx, wbuf)
+    plans[tag] = (key, plan)
+    return plan
+
+
 def packed_weight(mod, desc, weight=None, tag="w", adjoint=False):
-    """Packed half copy of ``mod.weight`` (or of ``weight(mod.weight)``, a rearranged form) for ``desc``."""
+    """Packed half copy of ``mod.weight`` (or of ``weight(mod.weight)``, a rearranged form) for ``desc``.
+    Cache entry: (key, packed, descriptor copy | None, adjoint, fp32 source of the pack, gather plan | None)."""
     src = mod.weight
     key = (tag, desc.dtype, src._version, src.data_ptr(), desc.Cin, desc.Cout, desc.kh, desc.kw, desc.transposed)
     cache = mod.__dict__.setdefault("_ir2rgb_packed", {})
     hit = cache.get(tag)
     if hit is not None and hit[0] == key:
         return hit[1]
+    plan = None
     with torch.no_grad():
-        w = src.detach() if weight is None else weight(src.detach())
+        if weight is None:
+            w = src.detach()
+        else:
+            plan = _gather_plan(mod, tag, weight, src) if src.dtype == torch.float32 and src.is_contiguous() else None
+            w = _gather(src.detach().view(-1), plan[0], plan[1]) if plan is not None else weight(src.detach())
         if w.dtype != torch.float32 or not w.is_contiguous():
             w = w.float().contiguous()
         packed = C.pack_weight(desc, w, adjoint=adjoint)
-    # a "plain" entry is packed straight from the parameter's own storage: WeightRepacker can refresh it in place
-    plain = weight is None and w.data_ptr() == src.data_ptr()
-    cache[tag] = (key, packed, C.ConvDesc.from_buffer_copy(desc) if plain else None, bool(adjoint))
+    # an entry packed from the parameter's own storage, or from a persistent rearranged copy that ONE gather launch
+    # refreshes, can be refreshed in place by WeightRepacker; anything else repacks lazily at its next use
+    managed = (weight is None and w.data_ptr() == src.data_ptr()) or plan is not None
+    cache[tag] = (key, packed, C.ConvDesc.from_buffer_copy(desc) if managed else None, bool(adjoint), w if managed else None, plan)
     return packed
 
 
 class WeightRepacker:
-    """Refreshes, with ONE launch, every plain packed-weight copy cached under ``modules`` (forward and
+    """Refreshes, with ONE launch, every managed packed-weight copy cached under ``modules`` (forward and
     data-gradient operands) -- call ``run()`` right after the optimizer step that changed the weights.
     Without it each layer repacks lazily at its next use, ~280 small launches per training window.
     The packed buffers are overwritten in place, so no autograd graph recorded before the step may be
-    run backward after it (torch itself refuses that for in-place updated parameters).  Entries packed
-    from a rearranged weight (separable heads, padded thin layers) keep their lazy path."""
+    run backward after it (torch itself refuses that for in-place updated parameters).  Rearranged weights (the first
+    layers' x-im2col form, zero-padded widths) are refreshed by one gather launch each into their persistent fp32 copy,
+    which the batched pack then reads; entries whose rearrangement is not a pure index map keep their lazy path."""
 
     def __init__(self, modules):
         self.modules = [m for root in modules for m in root.modules() if getattr(m, "weight", None) is not None]
@@ -71,7 +109,7 @@ class WeightRepacker:
         ent = []
         for m in self.modules:
             for tag, hit in m.__dict__.get("_ir2rgb_packed", {}).items():
-                if len(hit) == 4 and hit[2] is not None and hit[0][3] == m.weight.data_ptr():
+                if len(hit) == 6 and hit[2] is not None and hit[0][3] == m.weight.data_ptr():
                     ent.append((m, tag, hit))
         return ent
 
@@ -79,14 +117,18 @@ class WeightRepacker:
         ent = self._collect()
         if not ent:
             return 0
-        sig = tuple((id(m), tag, hit[1].data_ptr(), hit[0][3], hit[0][1]) for m, tag, hit in ent)
+        sig = tuple((id(m), tag, hit[1].data_ptr(), hit[0][3], hit[0][1], hit[4].data_ptr()) for m, tag, hit in ent)
         if sig != self.sig:      # first call, or a layer packed a new buffer since (new shape / first backward)
             by_dtype = {}
             for e in ent:
                 by_dtype.setdefault(e[2][0][1], []).append(e)
-            self.batch = [C.PackBatch([(hit[2], m.weight.detach(), hit[1], hit[3]) for m, tag, hit in es])
+            self.batch = [C.PackBatch([(hit[2], hit[4], hit[1], hit[3]) for m, tag, hit in es])
                           for es in by_dtype.values()]
             self.sig = sig
+        with torch.no_grad():
+            for m, tag, hit in ent:
+                if hit[5] is not None:
+                    _gather(m.weight.detach().view(-1), hit[5][0], hit[5][1])
         for b in self.batch:
             b.run()
         for m, tag, hit in ent:

@@ -250,9 +250,11 @@ def test_batched_repack_equals_lazy_repack():
         for net in tr.netG + [tr.netD] + tr.netD_T:
             for m in net.modules():
                 for tag, hit in getattr(m, "_ir2rgb_packed", {}).items():
-                    if len(hit) == 4 and hit[2] is not None:
+                    if len(hit) == 6 and hit[2] is not None:
                         assert hit[0][2] == m.weight._version, (type(m).__name__, tag)
-                        fresh = C.pack_weight(hit[2], m.weight.detach(), adjoint=hit[3])
+                        fresh = C.pack_weight(hit[2], hit[4], adjoint=hit[3])     # (hit[4]: the parameter, or its rearranged copy)
+                        if hit[5] is None:
+                            assert hit[4].data_ptr() == m.weight.data_ptr()
                         assert torch.equal(fresh.view(torch.int16), hit[1].view(torch.int16)), (type(m).__name__, tag)
                         n_plain += 1
                         kinds.add((tag, hit[3], hit[2].transposed, hit[2].kh, hit[2].stride_h))
