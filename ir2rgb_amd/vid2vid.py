@@ -35,6 +35,7 @@ DEFAULTS = dict(  # options/base_options.py, options/train_options.py (SURVEY se
     no_vgg=True,         # VGG19 perceptual loss off: the pretrained weights cannot be downloaded here (False: ir2rgb_amd.vgg,
                          # randomly initialised unless a torchvision state_dict is loaded into trainer.vgg_loss.vgg)
     shared_fake_forward=True,   # one netD forward on generated frames serves the D and the G loss (autograd.backward_flags)
+    resident_inputs=False,      # the window tensors are not written on the main stream (see reference_flows)
     reuse_skipped_flows=True,   # reference flows of temporally skipped frame pairs seen in an earlier window are kept, not recomputed
     allreduce_chunk_elems=32 * 1024 * 1024,   # fp32 elements per gradient all-reduce (128 MB)
     batched_D=True,      # (with shared_fake_forward) real | generated | raw frames go through a discriminator as ONE batch of sample groups
@@ -171,6 +172,10 @@ class FlowNet(torch.nn.Module):
             return flow.view(b, n, 2, h, w), conf.view(b, n, 1, h, w)
         return self.compute_flow_and_conf(input_A, input_B, side)
 
+    def will_replay(self, n, im):
+        """True when a call on ``n`` frame pairs shaped like ``im`` [., 3, H, W] would be a graph replay (no lazy work)."""
+        return isinstance(self._graphs.get(((n,) + tuple(im.shape[1:]), im.dtype, str(im.device))), tuple)
+
     def compute_flow_and_conf(self, im1, im2, side=None):
         """FlowNet2 is frozen, runs without autograd and with fixed shapes: ~330 small launches per call.
         After two eager calls at a shape the whole call (convolutions, operators, interpolations, the
@@ -202,6 +207,13 @@ class FlowNet(torch.nn.Module):
                       flush=True)
                 return self._flow_and_conf_eager(im1, im2)
         g, a, b, (flow, conf) = ent
+        if side is not None and torch.cuda.current_stream(im1.device) == side:
+            # the caller already works on the second stream (Vid2VidTrainer.reference_flows, resident inputs): no wait
+            a.copy_(im1)
+            b.copy_(im2)
+            g.replay()
+            self.ran_on = side
+            return flow.clone(), conf.clone()
         if side is not None:
             main = torch.cuda.current_stream(im1.device)
             side.wait_stream(main)
@@ -458,6 +470,7 @@ class Vid2VidTrainer:
     def reset_sequence(self):
         self.fake_B_prev = None          # pyramid of the last tG-1 generated frames
         self._pair_flows = {}            # temporal scale -> [(push count, flow, conf)] of its newest pairs (reference_flows)
+        self._early_on = False           # FlowNet2 ahead of the main stream (reference_flows)
         # histories of the four streams the temporal discriminators sub-sample (train_vid2vid.py:45-52: real_B_all,
         # fake_B_all, flow_ref_all, conf_ref_all), each in one preallocated device buffer (ir2rgb_amd.frames)
         ts, tD = self.t_scales, self.tD
@@ -633,6 +646,41 @@ class Vid2VidTrainer:
         (discriminator.py:281-283).  Both depend on real frames only, so batching them changes nothing
         numerically (FlowNet2 is per-sample, frozen, eval mode)."""
         ts = self.t_scales
+        # ``resident_inputs`` (the window tensors are not produced on the main stream: bench.py's synthetic sequence, a
+        # loader that prefetches on its own stream and has synchronised): the real-frame bookkeeping and FlowNet2's replay
+        # then run on the second stream WITHOUT waiting for the main stream, i.e. beside the previous window's optimizer
+        # step (2.7 ms of pure HBM streaming) as well as beside this window's generator forward.  Only for replays.
+        early = False
+        if side is not None and self.opt["resident_inputs"] and isinstance(self.flow_net, FlowNet) and real_B.shape[1] == 1:
+            early = self.flow_net.will_replay(self._count_pairs(real_B), real_B.reshape((-1,) + tuple(real_B.shape[2:])))
+        main = torch.cuda.current_stream(real_B.device) if real_B.is_cuda else None
+        if early:
+            if not self._early_on:                          # first time: the histories were last written on the main stream
+                side.wait_stream(main)
+                self._early_on = True
+            with torch.cuda.stream(side):
+                return self._reference_flows(real_B, real_B_prev, side)
+        if self._early_on:                                  # back to the main stream (a new shape: lazy work ahead)
+            main.wait_stream(side)
+            self._early_on = False
+        return self._reference_flows(real_B, real_B_prev, side)
+
+    def _count_pairs(self, real_B):
+        """Frame pairs FlowNet2 will see for this one-frame push (host arithmetic only: what _reference_flows is about to
+        assemble -- the frame itself, plus per temporal scale whose tuple exists the newest pair, or all tD-1 of them)."""
+        h, b = self.hist["real"], real_B.shape[0]
+        total, pushed = h.len + 1, h.pushed + 1
+        reuse = self.opt["reuse_skipped_flows"] and self.tD == 3
+        n = b
+        for s in range(1, self.t_scales):
+            step = self.tD ** s
+            if total - step * (self.tD - 1) >= 1:
+                hit = reuse and any(e[0] == pushed - step for e in self._pair_flows.get(s, []))
+                n += b * (1 if hit else self.tD - 1)
+        return n
+
+    def _reference_flows(self, real_B, real_B_prev, side):
+        ts = self.t_scales
         rb_s = self.hist["real"].push(real_B)
         pushed = self.hist["real"].pushed
         firsts, seconds, owners = [real_B.reshape((-1,) + tuple(real_B.shape[2:]))], [real_B_prev.reshape((-1,) + tuple(real_B.shape[2:]))], []
@@ -662,6 +710,16 @@ class Vid2VidTrainer:
         h, w = real_B.shape[-2:]
         flow_ref, conf_ref = flow[:n0].view(b, t, 2, h, w), conf[:n0].view(b, t, 1, h, w)
         extra, off = {}, n0
+        # FlowNet2 may have replayed on the second stream, which the main stream joins only before the losses
+        # (train_window): the concatenation below reads its result, so it has to be queued on that stream too
+        ran = getattr(self.flow_net, "ran_on", None) if isinstance(self.flow_net, FlowNet) else None
+        on_side = ran is not None and torch.cuda.current_stream(flow.device) != ran
+        with (torch.cuda.stream(ran) if on_side else contextlib.nullcontext()):
+            extra = self._assemble_pair_flows(flow, conf, owners, cached, n0, pushed, reuse, h, w)
+        return flow_ref, conf_ref, rb_s, extra
+
+    def _assemble_pair_flows(self, flow, conf, owners, cached, off, pushed, reuse, h, w):
+        extra = {}
         for s, bb, tt in owners:
             fl, cf = flow[off:off + bb * tt].view(bb, tt, 2, h, w), conf[off:off + bb * tt].view(bb, tt, 1, h, w)
             off += bb * tt
@@ -669,9 +727,12 @@ class Vid2VidTrainer:
                 keep = [e for e in self._pair_flows.get(s, []) if e[0] > pushed - self.tD ** s * (self.tD - 2)]
                 self._pair_flows[s] = keep + [(pushed, fl[:, -1:], cf[:, -1:])]
             if s in cached:                                              # (tD == 3: exactly one older pair)
+                if fl.is_cuda:
+                    for t in cached[s][1:]:
+                        t.record_stream(torch.cuda.current_stream(fl.device))   # (it may have been made on the other stream)
                 fl, cf = torch.cat([cached[s][1], fl], 1), torch.cat([cached[s][2], cf], 1)
             extra[s] = (fl, cf)
-        return flow_ref, conf_ref, rb_s, extra
+        return extra
 
     def skipped_frames(self, rb_s, extra_flows, fake_B, flow_ref, conf_ref):
         """get_all_skipped_frames, dense variant (discriminator.py:219-234, :273-283); the real-frame
@@ -763,7 +824,7 @@ class Vid2VidTrainer:
         real_B_prev, real_B = real_Bp[:, :-1], real_Bp[:, 1:]
         if ran_on is not None:                      # FlowNet2 replayed on the side stream: join it here
             torch.cuda.current_stream(input_B.device).wait_stream(ran_on)
-            for t in [flow_ref, conf_ref] + [x for pair in extra_flows.values() for x in pair]:
+            for t in [flow_ref, conf_ref] + [x for pair in extra_flows.values() for x in pair] + [x for x in rb_s if x is not None]:
                 t.record_stream(torch.cuda.current_stream(input_B.device))
         # compute_fake_B_prev (generator.py:283-287) AS THE REFERENCE'S LOOP EVALUATES IT.  train_vid2vid.py:60,:67-68
         # hands the previous window's pyramid LIST to model_g and afterwards to compute_fake_B_prev; in between,
