@@ -471,6 +471,7 @@ class Vid2VidTrainer:
         self.fake_B_prev = None          # pyramid of the last tG-1 generated frames
         self._pair_flows = {}            # temporal scale -> [(push count, flow, conf)] of its newest pairs (reference_flows)
         self._early_on = False           # FlowNet2 ahead of the main stream (reference_flows)
+        self._backward_done = None       # event: the previous window's backward passes are through
         # histories of the four streams the temporal discriminators sub-sample (train_vid2vid.py:45-52: real_B_all,
         # fake_B_all, flow_ref_all, conf_ref_all), each in one preallocated device buffer (ir2rgb_amd.frames)
         ts, tD = self.t_scales, self.tD
@@ -658,6 +659,13 @@ class Vid2VidTrainer:
             if not self._early_on:                          # first time: the histories were last written on the main stream
                 side.wait_stream(main)
                 self._early_on = True
+            import os
+            if self._backward_done is not None and os.environ.get("IR2RGB_FLOW_BOUND", "1") == "1":
+                # not before the previous window's generator backward pass is through: the host runs windows ahead of the
+                # GPU, and a FlowNet2 that started whenever it was issued would also share the chip with that pass's
+                # compute-bound convolutions (no gain, and it spoils bench.py's per-kernel brackets); beside the
+                # discriminators' latency-bound passes and the HBM-bound optimizer step it is what fills the chip
+                side.wait_event(self._backward_done)
             with torch.cuda.stream(side):
                 return self._reference_flows(real_B, real_B_prev, side)
         if self._early_on:                                  # back to the main stream (a new shape: lazy work ahead)
@@ -781,6 +789,10 @@ class Vid2VidTrainer:
                 autograd.backward_flags(self.netD_T if shared else [], autograd.SKIP_PARAM_GRADS, 1 if batched else None):
             loss_G.backward(retain_graph=shared, inputs=g_inputs)
         self.grads_G.all_reduce_async(self.world)
+        if self._early_on:           # (the next window's FlowNet2 may start from here on, see reference_flows)
+            if self._backward_done is None:
+                self._backward_done = torch.cuda.Event()
+            self._backward_done.record()
         with autograd.backward_flags(d_nets if shared else [], autograd.SKIP_INPUT_GRAD):
             loss_D.backward(inputs=self.grads_D.params if shared else None)
             self.grads_D.all_reduce_async(self.world)
