@@ -408,6 +408,10 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
             for (int hs = 0; hs < kcl * 2; ++hs) {
                 const unsigned char *patch = pbufs + (hs & 1) * C::PBUF;
                 auto step = [&]<int KY>(std::integral_constant<int, KY>) {
+                    // the previous step's fragment reads have returned before the barrier that hands its weight stage
+                    // (and, every third step, its patch buffer) back to the loaders: a raw s_barrier does not keep the
+                    // compiler from sinking their wait below it (conv_mfma.hip wait_stage; tools/check_lds_war.py)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                     const unsigned char *wst = wring + (ks % C::NSTW) * C::WST;
                     if constexpr (ADJ) prefetch_terms(patch, std::integral_constant<int, KY>{});
@@ -431,6 +435,7 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
     // ([pixel][TCO couts], 16-byte chunk c of pixel row p at position c ^ (p & (TCO/8 - 1)): conflict-free both ways)
     // so that global memory sees 16-byte stores, TCO/8 lanes per contiguous TCO*2-byte pixel row, instead of 8-byte
     // pieces 2 KB apart.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // every wave is past its last LDS read / its last DMA has landed: smem is reusable
     if constexpr (SPLIT > 1) {
         // Hand-over between the two workgroups of this tile: [tile][split][wave][mi][ni][lane] float4, 1 KB per store.
@@ -442,7 +447,9 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
         // workgroup -- measured 104 us instead of 49 for the launch.
         typedef __attribute__((ext_vector_type(4))) unsigned p3_u32x4;
         constexpr int PER = NCW * MI * NI * 64 * 16;       // bytes per partial tile
-        const p3_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(partials, 0, (int)0x7fffffff, 0x00020000);
+        // exact extent of the partial tiles ([tiles][SPLIT] x PER bytes; the host keeps it under 1 GB): an offset past it
+        // is dropped / reads zeros instead of touching a neighbour allocation
+        const p3_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(partials, 0, npt * nct * SPLIT * PER, 0x00020000);
         const unsigned mine = (unsigned)((tile * SPLIT + ksplit) * PER), other = (unsigned)((tile * SPLIT + (ksplit ^ 1)) * PER);
         if (!loader) {
 #pragma unroll

@@ -285,9 +285,15 @@ conv_igemm_body(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Wp,
     const bool late_dma = (g.variant & 1) && wave >= 4 && AHEAD >= 2;  // wave-uniform (SGPR)
 
     auto wait_stage = [&](int ks) {
-        // stage ks has landed for THIS wave once all but the newest LOADS*(AHEAD-1) (later stages) are done
-        if (AHEAD >= 2 && ks + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS * (AHEAD - 1)) : "memory");
-        else                           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // stage ks has landed for THIS wave once all but the newest LOADS*(AHEAD-1) (later stages) are done.
+        // lgkmcnt(0): this wave's fragment reads of stage ks-1 have RETURNED before it arrives at the barrier behind which
+        // the other waves restage that buffer.  A raw s_barrier is no fence: without the wait hipcc sinks the last reads'
+        // s_waitcnt (and the MFMAs that need them) below the barrier, and a read still in flight can lose against the
+        // other waves' LDS-DMA when something slows the LDS -- it did, in the 2-stage ring, with a second stream's
+        // bank-conflicted pack kernel resident on the same CU: rows 32..63 of a wave's weight fragment (read last) came
+        // from the step after next.  tools/check_lds_war.py checks every kernel's code for this.
+        if (AHEAD >= 2 && ks + 1 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LOADS * (AHEAD - 1)) : "memory");
+        else                           asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // ... and for every wave; also: everyone is done reading stage ks-1
     };
     constexpr int MI = THIN ? 2 : 4;       // 16-row output-channel fragments a wave multiplies
@@ -358,6 +364,7 @@ conv_igemm_body(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Wp,
 
     // ---------------- epilogue: bias, activation, BN statistics, NHWC store ----------------
     // acc[mi][ni][r]: cout = ct*TC + wc*64 + mi*16 + lq*4 + r ; pixel = pt*TP + wp*(TP/4) + ni*16 + l15
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (this wave's last fragment reads have returned, see wait_stage)
     __builtin_amdgcn_s_barrier();  // all waves are past their last LDS read: smem is reusable
     const int co_base = ct * TC + wc * 64 + lq * 4;
     long opix[NI];

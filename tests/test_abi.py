@@ -69,3 +69,17 @@ def test_missing_library_is_an_error(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU/eager fallback"):
         _lib.lib()
+
+
+def test_lds_dma_pipelines_wait_for_their_reads_before_each_barrier(built_lib):
+    """Every kernel that stages operands by LDS-DMA restages a ring stage one barrier after its last fragment read; that is
+    only safe if the reading wave has waited for those reads BEFORE the barrier (a raw s_barrier is no fence, and hipcc
+    sinks the wait below it when it can).  tools/check_lds_war.py walks the gfx950 code of the built objects: no barrier may
+    be reachable with LDS reads outstanding.  (Round 3: this was the cause of the two-stream first-forward corruption.)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_lds_war
+    res = check_lds_war.check()
+    assert sum(k for _, k, _ in res) >= 100, "the scan did not find the LDS-DMA kernels"
+    bad = {name: hits[:3] for _, _, f in res for name, hits in f.items()}
+    assert not bad, f"LDS reads outstanding at a barrier: {bad}"

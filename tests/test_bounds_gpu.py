@@ -91,22 +91,63 @@ def test_convolution_forward_and_weight_gradient_stay_in_bounds(dev, name, dtype
     assert torch.isfinite(dw1).all() and torch.equal(dw1, dw0)
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_reflect_adjoint_stays_in_bounds(dev, dtype):
+def _fwd_ws_guarded(desc, x, wp, y, stats):
+    """ir2rgb_conv2d_fwd_ws called directly with a guard-banded split-K workspace of exactly
+    ir2rgb_conv2d_fwd_workspace_bytes: zeros inside (the tickets start even), a canary pattern on both sides."""
+    import ctypes
+    from ir2rgb_amd import _lib
     from ir2rgb_amd import conv as C
+    lib = _lib.lib()
+    n = int(lib.ir2rgb_conv2d_fwd_workspace_bytes(ctypes.byref(desc)))
+    assert n >= 0
+    band = 1 << 16
+    buf = torch.full((n + 2 * band,), 0x5A, dtype=torch.uint8, device=x.device)
+    buf[band:band + n].zero_()
+    ws = buf[band:band + n]
+    rc = lib.ir2rgb_conv2d_fwd_ws(ctypes.byref(desc), C._p(x), C._p(wp), C._p(None), C._p(y), C._p(stats),
+                                  C._p(ws) if n else C._p(None), n, _lib.current_stream(x))
+    _lib.check(rc, "conv2d_fwd_ws")
+    torch.cuda.synchronize()
+    return n, bool((buf[:band] == 0x5A).all() and (buf[band + n:] == 0x5A).all())
+
+
+# name: (channels, H, W, expects a split-K workspace) -- shapes that MUST select the patch-staged kernel's in-place
+# reflect adjoint: H even, W a multiple of its 64-pixel tile, >= 200 tiles.  The first is the dominant kernel of the
+# training bench (roofline.kernel: 1024 -> 1024 @32x64, split variant 4), the second its unsplit form.
+ADJ_CASES = {"split_1024ch_32x64": (1024, 32, 64, True), "unsplit_256ch_64x128": (256, 64, 128, False)}
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("name", list(ADJ_CASES))
+def test_reflect_adjoint_stays_in_bounds(dev, name, dtype):
+    """The in-place reflect adjoint of conv3x3_patch_kernel (and, in the split form, its partial-tile hand-over through the
+    caller's workspace): operands inside NaN bands, output and workspace inside canary bands, bit-identical results."""
+    from ir2rgb_amd import conv as C
+    ch, h, w, split = ADJ_CASES[name]
     gen = torch.Generator().manual_seed(3)
-    gyv = _nhwc(1, 256, 37, 67, dtype, dev, gen)
-    wt = (torch.randn(256, 256, 3, 3, generator=gen) * 0.03).to(dev)
-    dadj = C.make_desc(gyv.shape, 256, 3, 1, 1, C.PAD_REFLECT_ADJ, dtype)
-    if C.kernel_name(dadj) != "conv3x3_patch_kernel":
-        pytest.skip("patch-staged kernel not selected for this shape")
-    wp = C.pack_weight(C.make_desc(gyv.shape, 256, 3, 1, 1, C.PAD_ZERO, dtype), wt, adjoint=True)
+    gyv = _nhwc(1, ch, h, w, dtype, dev, gen)
+    wt = (torch.randn(ch, ch, 3, 3, generator=gen) * 0.03).to(dev)
+    dadj = C.make_desc(gyv.shape, ch, 3, 1, 1, C.PAD_REFLECT_ADJ, dtype)
+    assert C.kernel_name(dadj) == "conv3x3_patch_kernel"
+    wp = C.pack_weight(C.make_desc(gyv.shape, ch, 3, 1, 1, C.PAD_ZERO, dtype), wt, adjoint=True)
     d0, _ = C.conv2d_fwd(dadj, gyv, wp)
     gi, gw = Guarded(gyv, float("nan")), Guarded(wp, float("nan"))
     go = Guarded(d0, 7.0)
-    d1, _ = C.conv2d_fwd(dadj, gi.t, gw.t, out=go.t)
-    torch.cuda.synchronize()
-    assert torch.isfinite(d1.float()).all() and torch.equal(d1, d0) and go.intact()
+    go.t.zero_()
+    nbytes, ws_intact = _fwd_ws_guarded(dadj, gi.t, gw.t, go.t, None)
+    assert (nbytes > 0) == split, "split-K form expected for the 1024-channel shape only"
+    assert ws_intact, "the split-K hand-over wrote outside its workspace"
+    assert torch.isfinite(go.t.float()).all() and torch.equal(go.t, d0) and go.intact()
+    assert gi.intact() and gw.intact()
+    # the forward twin of the same shape (reflect padding, BatchNorm partial sums) through the same guarded path
+    dfw = C.make_desc(gyv.shape, ch, 3, 1, 1, C.PAD_REFLECT, dtype)
+    assert C.kernel_name(dfw) == "conv3x3_patch_kernel"
+    wf = C.pack_weight(dfw, wt)
+    y0, s0 = C.conv2d_fwd(dfw, gyv, wf, None, want_stats=True)
+    gwf, gy, gs = Guarded(wf, float("nan")), Guarded(y0, 7.0), Guarded(s0, 7.0)
+    gy.t.zero_()
+    _, ws_intact = _fwd_ws_guarded(dfw, gi.t, gwf.t, gy.t, gs.t)
+    assert ws_intact and torch.equal(gy.t, y0) and torch.equal(gs.t, s0) and gy.intact() and gs.intact()
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

@@ -277,3 +277,43 @@ def test_correlation_nhwc_half_vs_oracle(dev, dtype, N, C, H, W, lda, offa):
     ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
     assert ((got.float() - want.float()).abs() <= ulp * want.float().abs() + 1e-6).all()
     assert (merged[:, :32] == 7.0).all() and (merged[:, 473:] == 7.0).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N", [1, 3])
+def test_correlation_nhwc_half_full_size(dev, dtype, N):
+    """ir2rgb_correlation_nhwc_half at the sizes the training window runs it (FlowNetC's conv3 outputs of a 512x1024 frame
+    pair: [N,256,64,128], N = pairs per window = 1..3; flownet2_hip.py, reference FlowNetC.py:31 + correlation_cuda_kernel.cu:73-147).
+    Absolute values: the C oracle on the half-rounded inputs restricted to the top and the bottom eight rows (displacement
+    rows tj <= 0 read f2 rows <= y only, tj >= 0 rows >= y only, so a crop leaves those planes unchanged), every sample;
+    everything in between: the fp32 operator of this package (itself pinned by the oracle) on the same inputs."""
+    from ir2rgb_amd import _lib, conv as CV
+    Correlation, _, _ = _mods()
+    C, H, W = 256, 64, 128
+    g = torch.Generator(device="cpu").manual_seed(10 + N)
+    fa = torch.randn(N, C, H, W, generator=g).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    fb = torch.randn(N, C, H, W, generator=g).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    out = torch.full((N, 441, H, W), float("nan"), dtype=torch.float32, device=dev)
+    rc = _lib.lib().ir2rgb_correlation_nhwc_half(CV._p(fa), C, 0, CV._p(fb), C, 0, CV._p(out), 0, 0, 0, 1.0, N, C, H, W,
+                                                 CV._TORCH2DT[dtype], _lib.current_stream(out))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    tol = 2e-6 * np.sqrt(C)
+    a32, b32 = fa.float().contiguous(), fb.float().contiguous()
+    o5 = out.view(N, 21, 21, H, W)
+    top = O.correlation_fwd(a32[:, :, :8].cpu().numpy(), b32[:, :, :8].cpu().numpy(), 20, 1, 20, 1, 2).reshape(N, 21, 21, 8, W)
+    close(o5[:, :11, :, :8], top[:, :11], atol=tol)
+    bot = O.correlation_fwd(a32[:, :, -8:].cpu().numpy(), b32[:, :, -8:].cpu().numpy(), 20, 1, 20, 1, 2).reshape(N, 21, 21, 8, W)
+    close(o5[:, 10:, :, -8:], bot[:, 10:], atol=tol)
+    ref = Correlation(20, 1, 20, 1, 2, 1)(a32, b32)
+    torch.testing.assert_close(out, ref, atol=2 * tol, rtol=0)
+    # the pipeline's form: half NHWC slice + LeakyReLU(0.1) inside a wider buffer
+    merged = torch.full((N, 512, H, W), 7.0, dtype=dtype, device=dev).contiguous(memory_format=torch.channels_last)
+    rc = _lib.lib().ir2rgb_correlation_nhwc_half(CV._p(fa), C, 0, CV._p(fb), C, 0, CV._p(merged), 1, 512, 32, 0.1, N, C, H, W,
+                                                 CV._TORCH2DT[dtype], _lib.current_stream(out))
+    assert rc == 0
+    want = torch.nn.functional.leaky_relu(out, 0.1).to(dtype)
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    assert ((merged[:, 32:473].float() - want.float()).abs() <= ulp * want.float().abs() + 1e-6).all()
+    assert (merged[:, :32] == 7.0).all() and (merged[:, 473:] == 7.0).all()
