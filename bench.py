@@ -102,6 +102,87 @@ def cpu_baseline(threads):
                       "their backward passes and Adam"}
 
 
+def _timed(fn, n, warm=3):
+    """Mean milliseconds of fn() over n back-to-back calls (HIP events on the current stream)."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def config5_forward(dev):
+    """BASELINE config 5: the two-scale generator forward at 1024x2048 in f16 (G0 composite ngf 128 @512x1024 feeding G1
+    composite-local ngf 64 @1024x2048; reference models/networks.py:103-317): 6.632 + 2.44 = 9.07 TFLOP of convolutions."""
+    from ir2rgb_amd import networks as N
+    from ir2rgb_amd.graphs import GraphedForward
+    opt = dict(gen_blocks=9, n_blocks_local=3, fg=False, no_flow=False, n_local_enhancers=1, feat_num=3)
+    torch.manual_seed(0)
+    g0 = N.build_generator_module(9, 3, 6, 128, "composite", 3, "batch", 0, **opt).to(dev).train()
+    g1 = N.build_generator_module(9, 3, 6, 64, "composite-local", 3, "batch", 1, **opt).to(dev).train()
+    g0.compute_dtype = g1.compute_dtype = torch.float16
+    h, w = 2 * H, 2 * W
+    x, p = torch.tanh(torch.randn(1, 9, h, w, device=dev)), torch.tanh(torch.randn(1, 6, h, w, device=dev))
+    x0, p0 = torch.nn.functional.avg_pool2d(x, 2), torch.nn.functional.avg_pool2d(p, 2)
+
+    def fwd(x0, p0, x, p):
+        o0 = g0(x0, p0, None, None, None, None, False)
+        return g1(x, p, None, o0[4], o0[5], None, False)[:4]
+
+    tflop = 6.632 + 2.44
+    out = {"algorithmic_TFLOP": tflop, "dtype": "f16"}
+    with torch.no_grad():
+        ms = _timed(lambda: fwd(x0, p0, x, p), 5)
+        out["eager"] = {"ms": round(ms, 3), "TFLOPs": round(tflop / ms * 1e3, 1), "frac_of_peak": round(tflop / ms * 1e3 / PEAK_TFLOPS, 4)}
+    gf = GraphedForward(fwd, x0, p0, x, p)
+    ms = _timed(lambda: gf(x0, p0, x, p), 10, warm=2)
+    out["hip_graph"] = {"ms": round(ms, 3), "TFLOPs": round(tflop / ms * 1e3, 1), "frac_of_peak": round(tflop / ms * 1e3 / PEAK_TFLOPS, 4)}
+    return out
+
+
+def config3_operators(dev):
+    """BASELINE config 3: the three FlowNet2 operators at the sizes a 512x1024 frame pair gives them (algorithmic
+    bytes 31.2 MB / 16.8 MB / 8.4 MB), back-to-back launches through the reference's operator API, HBM peak 8 TB/s."""
+    import ctypes
+    from ir2rgb_amd import _lib, conv as CV
+    from ir2rgb_amd.flownet2_pytorch.networks.channelnorm_package.channelnorm import ChannelNorm
+    from ir2rgb_amd.flownet2_pytorch.networks.correlation_package.correlation import Correlation
+    from ir2rgb_amd.flownet2_pytorch.networks.resample2d_package.resample2d import Resample2d
+    f1, f2 = torch.randn(1, 256, 64, 128, device=dev), torch.randn(1, 256, 64, 128, device=dev)
+    img, flow = torch.randn(1, 3, H, W, device=dev), torch.randn(1, 2, H, W, device=dev) * 4
+    corr, res, cn = Correlation(20, 1, 20, 1, 2, 1), Resample2d(), ChannelNorm()
+    out = {}
+    with torch.no_grad():
+        for name, fn, mb, gflop in (("correlation_fwd_fp32_nchw", lambda: corr(f1, f2), 31.2, 1.85),
+                                    ("resample2d_fwd", lambda: res(img, flow), 16.8, None),
+                                    ("channelnorm_fwd", lambda: cn(img), 8.4, None)):
+            us = _timed(fn, 50, warm=5) * 1e3
+            out[name] = {"us": round(us, 1), "GB_per_s": round(mb * 1e6 / (us * 1e-6) / 1e9, 0), "frac_of_hbm_peak": round(mb * 1e6 / (us * 1e-6) / 8e12, 3)}
+            if gflop:
+                out[name]["TFLOPs"] = round(gflop * 1e3 / us, 1)
+        # the form FlowNet2 runs inside this package: half NHWC feature maps -> banded MFMA products, fp32 planes out
+        a = f1.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        b = f2.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        o = torch.empty(1, 441, 64, 128, device=dev)
+        lib = _lib.lib()
+
+        def mf():
+            rc = lib.ir2rgb_correlation_nhwc_half(CV._p(a), 256, 0, CV._p(b), 256, 0, CV._p(o), 0, 0, 0, 1.0, 1, 256, 64, 128, CV.BF16,
+                                                  _lib.current_stream(o))
+            assert rc == 0
+        us = _timed(mf, 50, warm=5) * 1e3
+        mb = (2 * 4.19 + 14.45)
+        out["correlation_fwd_nhwc_half_mfma"] = {"us": round(us, 1), "GB_per_s": round(mb * 1e6 / (us * 1e-6) / 1e9, 0),
+                                                 "TFLOPs_useful": round(1.85e3 / us, 1)}
+    out["note"] = "API-level launches incl. the Python operator wrappers (allocation of the output); kernel-only times: profiles/"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -246,6 +327,14 @@ def main():
                 "ms": round(ms, 3), "TFLOPs": round(6.632 / ms * 1e3, 1), "frac_of_peak": round(6.632 / ms * 1e3 / PEAK_TFLOPS, 4)}
         except Exception as e:  # noqa: BLE001  an extra measurement must never take the bench line down
             extra["north_star_generator_forward_512x1024_hip_graph"] = {"error": f"{type(e).__name__}: {e}"}
+        del g
+        torch.cuda.empty_cache()
+        for name, fn in (("config5_two_scale_forward_1024x2048_f16", config5_forward), ("config3_flownet2_operators", config3_operators)):
+            try:
+                extra[name] = fn(dev)
+            except Exception as e:  # noqa: BLE001
+                extra[name] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
 
     frames = world * args.steps * 1  # n_frames_load = 1 frame per window per rank
     line = {

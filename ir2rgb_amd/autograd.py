@@ -23,6 +23,7 @@ from torch.autograd import Function
 from . import _lib
 from . import conv as C
 from . import layers as L
+from . import streamcheck as SC
 
 _DT = {torch.bfloat16: 1, torch.float16: 2}
 
@@ -306,6 +307,10 @@ def wgrad_overlapped(conv, fn, *inputs):
     dev = inputs[0].device
     param = conv.weight
     if not WGRAD_SIDE_STREAM or dev.type != "cuda" or not getattr(conv, "_ir2rgb_side_wgrad", False):
+        return fn()
+    if GRAD_SINKS and param in GRAD_SINKS:
+        # the gradient goes straight into the all-reduce buffer, and the hook that puts its chunk on the wire runs on the
+        # main stream: it must not overtake a kernel on the side stream
         return fn()
     if WGRAD_SIDE_SMALL_ONLY and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1) and \
             not isinstance(conv, torch.nn.ConvTranspose2d) and conv.in_channels >= 64:
@@ -641,6 +646,10 @@ class HeadFn(Function):
                     wcat = _pad_dim(torch.cat([c.weight.detach().float() for c in convs], 0), 1, cin)
                     wy = _pad_rows(L._ysplit_weight(wcat), CT).contiguous()      # [64][cin][1][kw] forward weight
                     cache["ysplit_adj"] = (key, C.pack_weight(desc, wy, adjoint=True))
+                    if SC.ENABLED:
+                        SC.produced(cache["ysplit_adj"][1], "packed head weight (adjoint)")
+            if SC.ENABLED:
+                SC.consumed(cache["ysplit_adj"][1], "packed head weight (adjoint)")
             dpad, _ = C.conv2d_fwd(desc, dT, cache["ysplit_adj"][1])
             gfeat = fold_reflect(dpad, 0, kw // 2)
         wdesc = C.make_desc(tuple(feat.shape), CT, (1, kw), 1, (0, kw // 2), C.PAD_REFLECT, feat.dtype)

@@ -9,6 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
+from . import streamcheck as SC
 from ._lib import ConvDesc
 
 BF16, F16 = 1, 2
@@ -188,6 +189,10 @@ def _fwd_workspace(desc, x):
     ws = _SPLIT_WS.get(k)
     if ws is None or ws.numel() < n:
         ws = _SPLIT_WS[k] = torch.zeros(n, dtype=torch.uint8, device=x.device)
+        if SC.ENABLED:
+            SC.produced(ws, "split-K workspace")
+    if SC.ENABLED:
+        SC.consumed(ws, "split-K workspace")
     return ws, n
 
 

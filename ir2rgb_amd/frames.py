@@ -15,6 +15,8 @@ serves its windows as zero-copy views.
 """
 import torch
 
+from . import streamcheck as SC
+
 
 class FrameHistory:
     """History of one frame stream ([B, T, C, H, W] pushes) with the reference's temporal sub-sampling.
@@ -69,8 +71,12 @@ class FrameHistory:
         n = B.shape[1]
         self.pushed += n
         self._reserve(B)
+        if SC.ENABLED:
+            SC.consumed(self.buf, "frame history")
         with torch.no_grad():
             self.buf[:, self.start + self.len:self.start + self.len + n].copy_(B)
+        if SC.ENABLED:
+            SC.produced(self.buf, "frame history")
         total = self.len + n                                            # frames of history + this push
         hist = self.buf[:, self.start:self.start + total]              # detached storage of all of them
         skipped = [None] * self.t_scales

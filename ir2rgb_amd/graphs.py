@@ -36,8 +36,7 @@ class GraphedForward:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            # the module is warm now (weights packed, caches built by the one-stream warm-up above): the capture may
-            # fork the generators' independent branches onto a second stream (ir2rgb_amd.networks.branch_streams)
+            # the capture forks the generators' independent branches onto a second stream (ir2rgb_amd.networks.branch_streams)
             from .networks import branch_streams
             with torch.cuda.graph(self.graph), branch_streams(two_streams):
                 self.static_out = fn(*self.static_in)

@@ -19,6 +19,7 @@ import torch.nn as nn
 
 from . import _lib
 from . import conv as C
+from . import streamcheck as SC
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 _DT = {torch.bfloat16: 1, torch.float16: 2}
@@ -37,9 +38,13 @@ def _require_gpu(t, what):
 # packed-weight cache
 # ---------------------------------------------------------------------------------------------
 def _gather(src, idx, dst):
+    if SC.ENABLED:
+        SC.consumed(src, "fp32 parameter"), SC.consumed(idx, "gather plan")
     with _lib.on_device(src):
         rc = _lib.lib().ir2rgb_gather_f32(_p(src), _p(idx), _p(dst), dst.numel(), _lib.current_stream(src))
     _lib.check(rc, "gather_f32")
+    if SC.ENABLED:
+        SC.produced(dst, "rearranged fp32 weight")
     return dst
 
 
@@ -74,8 +79,12 @@ def packed_weight(mod, desc, weight=None, tag="w", adjoint=False):
     cache = mod.__dict__.setdefault("_ir2rgb_packed", {})
     hit = cache.get(tag)
     if hit is not None and hit[0] == key:
+        if SC.ENABLED:
+            SC.consumed(hit[1], f"packed weight '{tag}'")
         return hit[1]
     plan = None
+    if SC.ENABLED:
+        SC.consumed(src, "fp32 parameter")
     with torch.no_grad():
         if weight is None:
             w = src.detach()
@@ -85,6 +94,8 @@ def packed_weight(mod, desc, weight=None, tag="w", adjoint=False):
         if w.dtype != torch.float32 or not w.is_contiguous():
             w = w.float().contiguous()
         packed = C.pack_weight(desc, w, adjoint=adjoint)
+    if SC.ENABLED:
+        SC.produced(packed, f"packed weight '{tag}'")
     # an entry packed from the parameter's own storage, or from a persistent rearranged copy that ONE gather launch
     # refreshes, can be refreshed in place by WeightRepacker; anything else repacks lazily at its next use
     managed = (weight is None and w.data_ptr() == src.data_ptr()) or plan is not None
@@ -129,8 +140,14 @@ class WeightRepacker:
             for m, tag, hit in ent:
                 if hit[5] is not None:
                     _gather(m.weight.detach().view(-1), hit[5][0], hit[5][1])
+        if SC.ENABLED:
+            for m, tag, hit in ent:
+                SC.consumed(m.weight, "fp32 parameter")
         for b in self.batch:
             b.run()
+        if SC.ENABLED:
+            for m, tag, hit in ent:
+                SC.produced(hit[1], f"packed weight '{tag}' (batched repack)")
         for m, tag, hit in ent:
             k = hit[0]
             m._ir2rgb_packed[tag] = ((k[0], k[1], m.weight._version) + tuple(k[3:]),) + tuple(hit[1:])
@@ -195,6 +212,10 @@ def bn_finalize(stats, count, bn, training=True, conv_bias=None, outs=None):
     track = training and bn.track_running_stats and bn.running_mean is not None
     momentum = 0.1 if bn.momentum is None else bn.momentum
     use_running = track or frozen
+    if SC.ENABLED and use_running:
+        SC.consumed(bn.running_mean, "BatchNorm running statistics")
+        if track:
+            SC.produced(bn.running_mean, "BatchNorm running statistics")
     with _lib.on_device(scale):
         rc = _lib.lib().ir2rgb_bn_finalize_ex(_p(stats), rows, ch, int(count), _p(bn.weight), _p(bn.bias), _p(conv_bias),
                                               _p(bn.running_mean) if use_running else _p(None),
@@ -228,6 +249,9 @@ def bn_finalize_apply(stats, count, bn, y, act, res1=None, res2=None, conv_bias=
         momentum, eps, trs = 0.1 if bn.momentum is None else float(bn.momentum), float(bn.eps), bn.track_running_stats
     track = trs and has_rm
     null = ctypes.c_void_p(0)
+    if SC.ENABLED and track:
+        SC.consumed(bn.running_mean, "BatchNorm running statistics")
+        SC.produced(bn.running_mean, "BatchNorm running statistics")
     with _lib.on_device(y):
         rc = _lib.lib().ir2rgb_bn_finalize_apply(_p(stats), rows, ch, int(count), pw, pb, _p(conv_bias),
                                                  prm if track else null, prv if track else null, momentum, eps,
@@ -393,7 +417,11 @@ def head_stage(feat, convs, acts, mul=1.0):
             if wcat.shape[1] != feat.shape[1]:      # the feature map runs at a padded width (autograd.padded_width)
                 wcat = torch.cat([wcat, wcat.new_zeros((wcat.shape[0], feat.shape[1] - wcat.shape[1]) + tuple(wcat.shape[2:]))], 1)
             cache["ysplit"] = (key, C.pack_weight(desc, _ysplit_weight(wcat).contiguous()))
+            if SC.ENABLED:
+                SC.produced(cache["ysplit"][1], "packed head weight")
     wp = cache["ysplit"][1]
+    if SC.ENABLED:
+        SC.consumed(wp, "packed head weight")
     t, _ = C.conv2d_fwd(desc, feat, wp, None, want_stats=False)
     bias = torch.cat([c.bias.detach().float() for c in convs], 0).contiguous()
     out = torch.empty((n, cout, h, w), dtype=torch.float32, device=feat.device)
@@ -434,5 +462,9 @@ def bn_apply_add(a, b):
         # shared by every later call on ANY stream (the generators run independent branches on two): the fills above
         # were queued on the current stream only, so make them visible to all streams once
         torch.cuda.synchronize(a.device)
+        if SC.ENABLED:
+            SC.produced(_UNIT[key][0], "unit scale"), SC.produced(_UNIT[key][1], "zero shift")
     one, zero = _UNIT[key]
+    if SC.ENABLED:
+        SC.consumed(one, "unit scale"), SC.consumed(zero, "zero shift")
     return bn_apply(a, one, zero, ACT_NONE, res1=b)

@@ -70,6 +70,23 @@ def _dst_key(t):
     return (t.data_ptr(), tuple(t.shape), t.dtype)
 
 
+# A destination is written ONCE per backward pass: a second term that differentiates the same piece in the same pass (the
+# real pair's logits enter both compute_loss_D calls of a window, discriminator.py:134,:143) gets a buffer of its own and
+# autograd adds the two -- two writes into one destination would make the engine sum two aliases of the LAST write.
+_DST_USED = set()
+
+
+def _take_dst(t):
+    key = _dst_key(t)
+    g = GRAD_DST.get(key)
+    if g is None or key in _DST_USED:
+        return None
+    if not _DST_USED:
+        torch.autograd.Variable._execution_engine.queue_callback(_DST_USED.clear)     # (when this backward pass ends)
+    _DST_USED.add(key)
+    return g
+
+
 class _FusedLossFn(Function):
     @staticmethod
     def forward(ctx, terms, nslots, dt, *tensors):
@@ -99,7 +116,7 @@ class _FusedLossFn(Function):
         for p in pos:
             g = None
             if ctx.needs_input_grad[3 + p]:
-                g = GRAD_DST.get(_dst_key(tensors[p])) if GRAD_DST else None
+                g = _take_dst(tensors[p]) if GRAD_DST else None
                 if g is None or g.stride() != tensors[p].stride():
                     g = torch.empty_like(tensors[p])
             grads.append(g)

@@ -170,30 +170,31 @@ def _real(x, channels):
 # kernels that are a few MB of traffic behind a dependent launch -- the chip idles through a fifth of the time.  Two
 # chains on two streams fill each other's gaps (the convolutions are MFMA-bound, the BatchNorm passes HBM- and
 # latency-bound).  Same kernels, same operands: results are bit-identical to the one-stream order
-# (tests/test_networks_gpu.py::test_branch_streams_are_bit_exact: varying inputs, both generators).
+# (tests/test_networks_gpu.py::test_branch_streams_are_bit_exact: varying inputs, both generators;
+# tests/test_streams_gpu.py: the first forward of fresh modules).
 # Measured on the 512x1024 single-scale forward (tools/prof_forward.py --graph): 7.07 -> 6.61 ms.
 #
-# OFF unless asked for (``branch_streams()`` context; ir2rgb_amd.graphs.GraphedForward asks after its warm-up).
-# KNOWN HAZARD, unresolved: a forward that still has lazy work to do -- packing the weights of a fresh module -- came
-# out locally wrong when run on two streams (8 .. 24 consecutive channels of a stage output off by up to 1.0, a
-# different stage every time, only when an earlier forward had populated the allocator's caches; never on one
-# stream, never once the module is warm, also with NaN-poisoned caches and with varying inputs; device-wide
-# synchronisation at the fork and the join does not remove it, serialising the lazy work does:
-# tools/branch_race*.py).  The regime that is verified bit-exact is the warm module, so that is the only regime
-# that gets two streams.  Under autograd ("1") torch replays every node on the stream its forward ran on, so
-# loss.backward() overlaps the same way: 37.4 -> 36.4 ms per training window measured, not enabled by default
-# (same hazard for the first window, and bench.py's per-kernel roofline bracket would time two kernels sharing the chip).
+# IR2RGB_BRANCH_STREAMS: "auto" (default) = autograd-free forwards take two streams, forwards that record a graph stay
+# on one; "1" = always; "0" = never; ``branch_streams()`` overrides it for a block.  Under autograd torch replays every
+# node on the stream its forward ran on, so loss.backward() would overlap the same way (37.4 -> 36.4 ms per training
+# window measured); the trainer keeps one stream because bench.py's per-kernel roofline bracket must time kernels that
+# have the chip to themselves.
+# History: round 2 confined two streams to warm modules after a fresh module's first forward came out locally wrong
+# (8-24 consecutive channels of a stage off, a different stage every time).  Round 3 found the cause -- not a stream-
+# ordering bug at all: a write-after-read race INSIDE the convolution kernels' LDS rings that needs an LDS-heavy kernel of
+# another stream on the same CU to show (the cold forward's weight-packing kernel); see conv_mfma.hip wait_stage,
+# tools/check_lds_war.py and DESIGN.md section 8.  With that fixed the restriction is gone.
 # ---------------------------------------------------------------------------------------------
 import contextlib as _contextlib
 import os as _os
 
-BRANCH_STREAMS = _os.environ.get("IR2RGB_BRANCH_STREAMS", "0")      # "0" off | "1" on | set by branch_streams()
+BRANCH_STREAMS = _os.environ.get("IR2RGB_BRANCH_STREAMS", "auto")   # "auto" | "1" | "0" | set by branch_streams()
 _SIDE_STREAMS = {}
 
 
 @_contextlib.contextmanager
 def branch_streams(enabled=True):
-    """Run the generators' independent branches on two HIP streams inside this context (warm modules only, see above)."""
+    """Run the generators' independent branches on two HIP streams inside this context (or, ``enabled=False``, on one)."""
     global BRANCH_STREAMS
     old, BRANCH_STREAMS = BRANCH_STREAMS, "1" if enabled else "0"
     try:
@@ -208,7 +209,8 @@ class _Branch:
 
     def __init__(self, *inputs):
         self.inputs = [t for t in inputs if isinstance(t, torch.Tensor)]
-        self.enabled = BRANCH_STREAMS == "1" and bool(self.inputs) and self.inputs[0].is_cuda
+        on = BRANCH_STREAMS == "1" or (BRANCH_STREAMS == "auto" and not torch.is_grad_enabled())
+        self.enabled = on and bool(self.inputs) and self.inputs[0].is_cuda
         self.ctx = None
 
     def __enter__(self):

@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from . import streamcheck as SC
 
 
 class FusedAdam:
@@ -98,6 +99,9 @@ class FusedAdam:
             raise ValueError("FusedAdam.load_state_dict: parameters with different step counts (one launch updates all)")
         self.step_count = steps.pop() if steps else 0
         with torch.no_grad():
+            if not sd["state"]:         # a state saved before the first step: start from zero moments, as torch.optim.Adam does
+                self.exp_avg.zero_()
+                self.exp_avg_sq.zero_()
             for i, s in sd["state"].items():
                 m, v = self.moments(int(i))
                 m.copy_(s["exp_avg"])
@@ -137,3 +141,6 @@ class FusedAdam:
         # the kernel wrote the parameters behind autograd's back: bump their version counters so that
         # caches keyed on them (the packed MFMA weights of ir2rgb_amd.layers) are refreshed
         torch.autograd.graph.increment_version(self.params)
+        if SC.ENABLED:
+            for p in self.params:
+                SC.produced(p, "fp32 parameter (Adam step)")

@@ -21,6 +21,7 @@ import torch.distributed as dist
 import torch.nn.functional as F
 
 from . import autograd, layers, networks
+from . import streamcheck as SC
 from .losses import fused_losses
 from .optim import FusedAdam
 from .ext import warp_diff_norm
@@ -213,7 +214,10 @@ class FlowNet(torch.nn.Module):
             b.copy_(im2)
             g.replay()
             self.ran_on = side
-            return flow.clone(), conf.clone()
+            out = flow.clone(), conf.clone()
+            if SC.ENABLED:
+                SC.produced(out[0], "reference flow (FlowNet2 replay)"), SC.produced(out[1], "flow confidence (FlowNet2 replay)")
+            return out
         if side is not None:
             main = torch.cuda.current_stream(im1.device)
             side.wait_stream(main)
@@ -222,6 +226,8 @@ class FlowNet(torch.nn.Module):
                 b.copy_(im2)
                 g.replay()
                 out = flow.clone(), conf.clone()
+                if SC.ENABLED:
+                    SC.produced(out[0], "reference flow (FlowNet2 replay)"), SC.produced(out[1], "flow confidence (FlowNet2 replay)")
             for t in (im1, im2):
                 t.record_stream(side)
             self.ran_on = side
@@ -296,9 +302,10 @@ class FlatGrads:
         # early chunks: [lo, hi) ranges of the sink region, each a list of parameter indices; a chunk is all-reduced from
         # the autograd hook of the parameter whose gradient completes it (all_reduce_async picks up what is left)
         self.chunks, self._fired, self._pending, self._issued, self._world = [], set(), [], [], world
+        self._direct_capable, self._sink_ids = self.direct, []
         if self.direct:
             cur, lo = [], 0
-            sink_ids = [i for i in order if is_sink[i]]
+            sink_ids = self._sink_ids = [i for i in order if is_sink[i]]
             for k, i in enumerate(sink_ids):
                 cur.append(i)
                 hi = starts[i] + pad4(self.params[i].numel())
@@ -313,6 +320,22 @@ class FlatGrads:
                 p.register_post_accumulate_grad_hook(self._make_hook(i, chunk_of[i]))
         else:
             self.sink_end = 0
+
+    def set_direct(self, on):
+        """Arm / disarm the in-place sinks for the backward passes to come.  They are only sound while every parameter
+        receives ONE contribution per pass: a window that generates several frames applies each generator several times,
+        and a second contribution would overwrite the first in the same slice (autograd then sums two aliases of it) --
+        the trainer switches to the gathered form for such windows (Vid2VidTrainer.generate)."""
+        on = bool(on) and self._direct_capable
+        if on == self.direct:
+            return
+        self.direct = on
+        for i in self._sink_ids:
+            if on:
+                autograd.GRAD_SINKS[self.params[i]] = self.views[i]
+            else:
+                autograd.GRAD_SINKS.pop(self.params[i], None)
+        self._pending, self._issued = [], []
 
     def _make_hook(self, i, c):
         def hook(p):
@@ -486,10 +509,12 @@ class Vid2VidTrainer:
         n_load = real_A_all.size(1) - tG + 1
         if self._side_wgrad != (n_load == 1):
             # every generator is applied once per backward pass when one frame is generated per window:
-            # only then may its weight gradients run on the side stream (ir2rgb_amd.autograd)
+            # only then may its weight gradients run on the side stream (ir2rgb_amd.autograd) ...
             self._side_wgrad = n_load == 1
             for g in self.netG:
                 autograd.enable_side_wgrad(g, self._side_wgrad)
+        # ... and only then may they be written straight into the all-reduce buffer (FlatGrads.set_direct)
+        self.grads_G.set_direct(n_load == 1)
         first = self.fake_B_prev is None
         if not first:
             fake_pyr = list(self.fake_B_prev)
@@ -574,7 +599,14 @@ class Vid2VidTrainer:
         how often its batch statistics enter the running statistics; ``order``: the order the groups' statistics enter
         them in).  Callers put the generated frames FIRST: the generator's backward pass then works on the leading
         groups only (autograd.backward_flags(active_groups=...)).  -> one prediction pyramid per input."""
+        from . import losses as _losses
         G = len(inputs)
+        # gradient destinations registered by this network's previous forward are dropped here: an entry lives from one
+        # forward of a network to its next, whoever the caller is (losses.GRAD_DST is keyed by address)
+        keys = self.__dict__.setdefault("_dst_keys", {})
+        for k in keys.pop(id(netD), ()):
+            _losses.GRAD_DST.pop(k, None)
+        before = set(_losses.GRAD_DST)
         with layers.repeated_forward(tuple(repeats)):
             out = netD(torch.cat(inputs, 0), sample_groups=G, group_order=order)
         owner = next(m for m in netD.modules() if isinstance(m, torch.nn.Conv2d))
@@ -583,6 +615,7 @@ class Vid2VidTrainer:
             for t in scale:
                 for g, piece in enumerate(split_groups(t, G, owner)):
                     preds[g][i].append(piece)
+        keys[id(netD)] = [k for k in _losses.GRAD_DST if k not in before]
         return preds
 
     def image_losses(self, real_B, fake_B, fake_B_raw, real_A, real_B_prev, fake_B_prev, flow, weight, flow_ref, conf_ref):
@@ -734,10 +767,16 @@ class Vid2VidTrainer:
             if reuse:       # the newest pair's result serves the windows to come (tD - 2 more uses, tD**s pushes apart)
                 keep = [e for e in self._pair_flows.get(s, []) if e[0] > pushed - self.tD ** s * (self.tD - 2)]
                 self._pair_flows[s] = keep + [(pushed, fl[:, -1:], cf[:, -1:])]
+                if SC.ENABLED:
+                    SC.consumed(flow, "reference flow (FlowNet2 replay)")
+                    SC.produced(fl[:, -1:], "kept pair flow"), SC.produced(cf[:, -1:], "kept pair confidence")
             if s in cached:                                              # (tD == 3: exactly one older pair)
                 if fl.is_cuda:
                     for t in cached[s][1:]:
                         t.record_stream(torch.cuda.current_stream(fl.device))   # (it may have been made on the other stream)
+                if SC.ENABLED:
+                    SC.consumed(flow, "reference flow (FlowNet2 replay)")
+                    SC.consumed(cached[s][1], "kept pair flow"), SC.consumed(cached[s][2], "kept pair confidence")
                 fl, cf = torch.cat([cached[s][1], fl], 1), torch.cat([cached[s][2], cf], 1)
             extra[s] = (fl, cf)
         return extra
@@ -822,8 +861,8 @@ class Vid2VidTrainer:
         # The reference flows depend on real frames only (train_vid2vid.py:62-65 computes them after the generator, from
         # real_Bp = input_B[:, tG-2:]): FlowNet2 -- frozen, no autograd, replayed from a HIP graph from its third call at a
         # shape on -- runs on a second HIP stream BESIDE the generator forward and is joined before the losses that read
-        # its result (-1.0 ms per window).  Calls that are not yet replays (eager warm-up, capture: lazy work, see the
-        # hazard note in ir2rgb_amd/networks.py) run on the main stream, before the generator.
+        # its result (-1.0 ms per window).  Calls that are not yet replays (eager warm-up, capture) run on the main
+        # stream, before the generator: a capture has to own its stream.
         tG = self.opt["n_input_gen_frames"]
         real_Bp_in = input_B[:, tG - 2:]
         side = self._flow_stream(input_B)
@@ -850,6 +889,8 @@ class Vid2VidTrainer:
         if fake_B.size(1) > 1:
             fbp = torch.cat([fbp, fake_B[:, :-1].detach()], 1)
         flat = lambda t: t.reshape((-1,) + tuple(t.shape[2:]))  # noqa: E731
+        if SC.ENABLED:      # the losses read FlowNet2's results on this stream
+            SC.consumed(flow_ref, "reference flow (FlowNet2 replay)"), SC.consumed(conf_ref, "flow confidence (FlowNet2 replay)")
         L = self.image_losses(flat(real_B), flat(fake_B), flat(fake_B_raw), flat(real_A), flat(real_B_prev), flat(fbp),
                               flat(flow), flat(weight), flat(flow_ref), flat(conf_ref))
         rb_s, fb_s, fl_s, cf_s = self.skipped_frames(rb_s, extra_flows, fake_B, flow_ref, conf_ref)

@@ -268,10 +268,9 @@ def test_padded_width_gradients_have_reference_shapes(dev):
 
 @pytest.mark.parametrize("model", ["composite", "composite-local"])
 def test_branch_streams_are_bit_exact(dev, model):
-    """ir2rgb_amd.networks.branch_streams: the two independent branches of a WARM generator on two HIP streams give
+    """ir2rgb_amd.networks.branch_streams: the two independent branches of a generator on two HIP streams give
     bit-identical results to the one-stream order, for inputs that change from call to call (a stale read of anything a
-    previous call left behind would show) -- the regime GraphedForward uses them in.  (The regime that is NOT safe, a
-    forward with lazy weight packing still to do, is documented in ir2rgb_amd/networks.py and never gets two streams.)"""
+    previous call left behind would show).  (The first forward of a FRESH module: tests/test_streams_gpu.py.)"""
     from ir2rgb_amd import networks as N
     local = model == "composite-local"
     torch.manual_seed(0)
@@ -279,6 +278,7 @@ def test_branch_streams_are_bit_exact(dev, model):
     g.compute_dtype = torch.float16
     gen = torch.Generator().manual_seed(1)
     H, W = 256, 512
+    default = N.BRANCH_STREAMS
     for it in range(6):
         A, P = torch.rand(1, 9, H, W, generator=gen).to(dev) * (1 + it), torch.rand(1, 6, H, W, generator=gen).to(dev)
         fi = ff = None
@@ -286,12 +286,13 @@ def test_branch_streams_are_bit_exact(dev, model):
             mk = lambda: torch.rand(1, 128, H // 2, W // 2, generator=gen).to(dev).half().contiguous(memory_format=torch.channels_last)  # noqa: E731
             fi, ff = mk() * (it + 1), mk()
         with torch.no_grad():
-            one = [t.clone() for t in g(A, P, None, fi, ff, None, False)[:6]]      # (the first call warms the module)
+            with N.branch_streams(False):
+                one = [t.clone() for t in g(A, P, None, fi, ff, None, False)[:6]]
             with N.branch_streams():
                 two = [t.clone() for t in g(A, P, None, fi, ff, None, False)[:6]]
         torch.cuda.synchronize()
         assert all(torch.equal(a, b) for a, b in zip(one, two)), f"call {it}"
-    assert N.BRANCH_STREAMS == "0"
+    assert N.BRANCH_STREAMS == default
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

@@ -1,0 +1,76 @@
+"""The data-parallel code path on librccl itself, with the one GPU a development box has: a process group of ONE rank on
+backend "nccl" (= RCCL on ROCm), the trainer told it is one of two ranks.  Everything that only ever ran on gloo before
+executes here against RCCL's stream semantics: ReduceOp.AVG, asynchronous collectives issued from autograd hooks while the
+backward pass is running, waits before the Adam steps, gradients written straight into the all-reduce buffer, FlowNet2
+captured into a HIP graph in thread-local mode next to the process group's watchdog thread and replayed on its own stream
+(IR2RGB_FLOW_STREAM_DP=1).  With one rank the average is the identity, so gradients and parameters must equal those of
+the plain single-process trainer BIT FOR BIT.  What this cannot show is xGMI bandwidth or a multi-rank schedule:
+those stay unmeasured until the driver's 8-GPU run."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", IR2RGB_FLOW_STREAM_DP="1")
+    import torch.distributed as dist
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from ir2rgb_amd import vid2vid as V
+    kw = dict(seed=0, first_layer_gen_filters=64, gen_blocks=2, allreduce_chunk_elems=1 << 20, resident_inputs=True)
+    tr = V.Vid2VidTrainer(dev, world_size=2, **kw)        # the N > 1 code path: sinks, hooks, AVG, async handles
+    twin = V.Vid2VidTrainer(dev, world_size=1, **kw)
+    assert tr.grads_G._direct_capable and not twin.grads_G._direct_capable
+    reduced = []
+    orig_reduce = V.FlatGrads._reduce
+    V.FlatGrads._reduce = lambda self, lo, hi: (reduced.append((bool(self._pending), hi - lo)), orig_reduce(self, lo, hi))[1]
+    A, B = V.synthetic_sequence(10, 64, 128, 7, dev)
+    res = {"windows": 8}
+    for w in range(8):
+        la = tr.train_window(A[:, w:w + 3], B[:, w:w + 3])
+        lb = twin.train_window(A[:, w:w + 3], B[:, w:w + 3])
+        torch.cuda.synchronize()
+        res[f"loss_equal_{w}"] = all(torch.equal(la[k], lb[k]) for k in lb)
+    V.FlatGrads._reduce = orig_reduce
+    for name, ma, mb in (("G", tr.netG, twin.netG), ("D", [tr.netD], [twin.netD]), ("DT", tr.netD_T, twin.netD_T)):
+        ga = torch.cat([p.grad.reshape(-1) for m in ma for p in m.parameters()])
+        gb = torch.cat([p.grad.reshape(-1) for m in mb for p in m.parameters()])
+        pa = torch.cat([p.detach().reshape(-1) for m in ma for p in m.parameters()])
+        pb = torch.cat([p.detach().reshape(-1) for m in mb for p in m.parameters()])
+        res[name + "_grads_equal"], res[name + "_params_equal"] = bool(torch.equal(ga, gb)), bool(torch.equal(pa, pb))
+    n_g = sum(p.numel() for m in tr.netG for p in m.parameters())
+    res["early_fraction_of_G"] = sum(n for armed, n in reduced if armed) / (8 * n_g)
+    res["flow_graph_replayed_on_side_stream"] = bool(tr._early_on) and tr.flow_net.ran_on is not None
+    res["backend"] = dist.get_backend()
+    torch.save(res, os.path.join(outdir, "rccl.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_rank_rccl_window_equals_single_process(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    mp.spawn(_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    res = torch.load(os.path.join(str(tmp_path), "rccl.pt"))
+    print(res)
+    assert res["backend"] == "nccl"
+    assert all(res[f"loss_equal_{w}"] for w in range(res["windows"])), res
+    for name in ("G", "D", "DT"):
+        assert res[name + "_grads_equal"] and res[name + "_params_equal"], res
+    assert res["early_fraction_of_G"] > 0.8, res          # the chunks left from the autograd hooks, through RCCL
+    assert res["flow_graph_replayed_on_side_stream"], res

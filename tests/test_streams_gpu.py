@@ -81,7 +81,69 @@ def test_first_forward_of_a_fresh_module_on_two_streams(dev, model):
             with N.branch_streams():
                 two = ga(A, P, None, fi, ff, None, False)[:6]
             torch.cuda.synchronize()
-            one = gb(A, P, None, fi, ff, None, False)[:6]
+            with N.branch_streams(False):
+                one = gb(A, P, None, fi, ff, None, False)[:6]
         torch.cuda.synchronize()
         assert all(torch.equal(a, b) for a, b in zip(one, two)), f"fresh module {it}"
         del ga, gb, one, two
+
+
+def test_stream_check_catches_an_unordered_use_and_accepts_an_ordered_one(dev):
+    """ir2rgb_amd.streamcheck (IR2RGB_STREAM_CHECK=1): a cached buffer written on one stream and read on another without a
+    wait in between raises; with wait_stream / an event / a host synchronisation in between it does not."""
+    from ir2rgb_amd import streamcheck as SC
+    SC.enable()
+    try:
+        side = torch.cuda.Stream(dev)
+        buf = torch.zeros(16, device=dev)
+        with torch.cuda.stream(side):
+            buf.add_(1)
+            SC.produced(buf, "planted buffer")
+        with pytest.raises(SC.StreamOrderError):
+            SC.consumed(buf)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        SC.consumed(buf)                                   # ordered by wait_stream
+        with torch.cuda.stream(side):
+            buf.add_(1)
+            SC.produced(buf, "planted buffer")
+            ev = torch.cuda.Event()
+            ev.record()
+        with pytest.raises(SC.StreamOrderError):
+            SC.consumed(buf)
+        torch.cuda.current_stream(dev).wait_event(ev)
+        SC.consumed(buf)                                   # ordered by the event
+        with torch.cuda.stream(side):
+            buf.add_(1)
+            SC.produced(buf, "planted buffer")
+        torch.cuda.synchronize()
+        SC.consumed(buf)                                   # ordered by the host
+        third = torch.cuda.Stream(dev)
+        with torch.cuda.stream(third):
+            SC.consumed(buf)                               # a stream created after the host wait is ordered after it too
+    finally:
+        SC.disable()
+    assert torch.cuda.Stream.wait_stream.__name__ != "wait_stream" or not SC.ENABLED
+
+
+def test_sixteen_training_windows_under_the_stream_check(dev):
+    """The whole loop on its three streams (main; FlowNet2 replaying ahead of it beside the previous window's optimizer
+    step; kept pair flows crossing windows and streams; the batched repack) with every cached buffer tagged by its producing
+    stream: no un-ordered cross-stream use in sixteen windows, and the check really saw cross-stream uses."""
+    from ir2rgb_amd import streamcheck as SC
+    from ir2rgb_amd import vid2vid as V
+    SC.enable()
+    try:
+        A, B = V.synthetic_sequence(18, 64, 128, 3, dev)
+        tr = V.Vid2VidTrainer(dev, seed=0, first_layer_gen_filters=64, gen_blocks=2, resident_inputs=True)
+        for w in range(16):
+            out = tr.train_window(A[:, w:w + 3], B[:, w:w + 3])
+        torch.cuda.synchronize()
+        assert tr._early_on and all(torch.isfinite(v).all() for v in out.values())
+        assert SC.STATS["cross_stream"] > 0 and SC.STATS["produced"] > 1000, SC.STATS
+        # ... and an inference forward on two streams right after the training step that rewrote the weights
+        with torch.no_grad():
+            b, t, c, h, w_ = A[:, :3].shape
+            tr.netG[0](A[:, :3].reshape(b, -1, h, w_), B[:, :2].reshape(b, -1, h, w_), None, None, None, None, False)
+        torch.cuda.synchronize()
+    finally:
+        SC.disable()
