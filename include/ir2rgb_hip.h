@@ -324,8 +324,11 @@ int ir2rgb_fold_reflect(const void *dxpad, void *dx, int N, int H, int W, int C,
 /* Backward of ir2rgb_head_finish: gout/out [N,Cout,H,W] fp32 (out = the forward result) ->
  * dT [N,H,W,CT] half (gradient w.r.t. the separable row responses, channels >= Cout*KH zeroed)
  * and dbias [Cout] fp32. */
-int ir2rgb_head_finish_bwd(const float *gout, const float *out, void *dT, float *dbias, int N, int H, int W, int Cout,
-                           int KH, int CT, int pad_h, unsigned acts, float mul, int dtype, void *stream);
+int ir2rgb_head_finish_bwd(const float *gout, const float *out, void *dT, float *dbias, float *partial, int N, int H, int W,
+                           int Cout, int KH, int CT, int pad_h, unsigned acts, float mul, int dtype, void *stream);
+/* Rows of 8 floats `partial` must hold for ir2rgb_head_finish_bwd (one per workgroup: the bias gradient is summed in a
+ * fixed order by a second, one-workgroup kernel -- no float atomics, bit-reproducible). */
+int ir2rgb_head_finish_bwd_rows(int N, int H, int W);
 
 /* Backward of ir2rgb_warp_blend_fwd w.r.t. raw, flow and w (prev is a detached input on the
  * training path, reference generator.py:153-154). */

@@ -85,7 +85,8 @@ PROTOTYPES = {
     "ir2rgb_bn_bwd": (c_int, [P] * 10 + [c_long, c_int, c_int, c_int, P]),
     "ir2rgb_thin_grad_expand": (c_int, [P, P, P, P] + [c_int] * 5 + [P]),
     "ir2rgb_fold_reflect": (c_int, [P, P] + [c_int] * 7 + [P]),
-    "ir2rgb_head_finish_bwd": (c_int, [P, P, P, P] + [c_int] * 7 + [ctypes.c_uint, c_float, c_int, P]),
+    "ir2rgb_head_finish_bwd": (c_int, [P, P, P, P, P] + [c_int] * 7 + [ctypes.c_uint, c_float, c_int, P]),
+    "ir2rgb_head_finish_bwd_rows": (c_int, [c_int, c_int, c_int]),
     "ir2rgb_warp_blend_bwd": (c_int, [P] * 8 + [c_int] * 4 + [P]),
     "ir2rgb_xexpand_bwd": (c_int, [P, P] + [c_int] * 10 + [P]),
     "ir2rgb_conv2d_wgrad_workspace_elems": (c_long, [_pdesc]),

@@ -626,11 +626,15 @@ class HeadFn(Function):
         gout = gout.float().contiguous()
         dT = C.empty_nhwc(n, CT, h, w, feat.dtype, feat.device)
         dbias = torch.empty(cout, dtype=torch.float32, device=feat.device)
+        rows = _lib.lib().ir2rgb_head_finish_bwd_rows(n, h, w)
+        if rows < 0:
+            _lib.check(rows, "head_finish_bwd_rows")
+        partial = torch.empty((rows, 8), dtype=torch.float32, device=feat.device)
         packed_acts = 0
         for i, a in enumerate(acts):
             packed_acts |= (a & 15) << (4 * i)
         with _lib.on_device(feat):
-            rc = _lib.lib().ir2rgb_head_finish_bwd(_p(gout), _p(out), _p(dT), _p(dbias), n, h, w, cout, kh, CT, kh // 2,
+            rc = _lib.lib().ir2rgb_head_finish_bwd(_p(gout), _p(out), _p(dT), _p(dbias), _p(partial), n, h, w, cout, kh, CT, kh // 2,
                                                    packed_acts, float(mul), _DT[feat.dtype], _lib.current_stream(feat))
         _lib.check(rc, "head_finish_bwd")
         spec = dict(k=(1, kw), stride=(1, 1), pad=(0, kw // 2), pad_mode=C.PAD_REFLECT, transposed=False)

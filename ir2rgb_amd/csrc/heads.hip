@@ -95,7 +95,7 @@ warp_blend_kernel(const float *__restrict__ raw, const float *__restrict__ prev,
 template <int DT>
 __global__ void __launch_bounds__(256)
 head_finish_bwd_kernel(const float *__restrict__ gout, const float *__restrict__ out, uint16_t *__restrict__ dT,
-                       float *__restrict__ dbias, int H, int W, int Cout, int KH, int CT, int pad, unsigned acts,
+                       float *__restrict__ partial, int H, int W, int Cout, int KH, int CT, int pad, unsigned acts,
                        float mul, long total) {
     const long hw = (long)H * W;
     float bsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -137,14 +137,33 @@ head_finish_bwd_kernel(const float *__restrict__ gout, const float *__restrict__
         }
         while (c < CT) put(0.f);
     }
-    // block reduction of the bias sums -> one atomic per block per channel
+    // block reduction of the bias sums -> one row of the partial buffer per block (summed in a fixed order by
+    // head_bias_sum_kernel: float atomics made the bias gradients differ in the last bit from run to run)
     __shared__ float red[8][256];
     for (int co = 0; co < Cout; ++co) red[co][threadIdx.x] = bsum[co];
     __syncthreads();
-    if (threadIdx.x < Cout) {
+    if (threadIdx.x < 8) {
         float s = 0.f;
-        for (int i = 0; i < 256; ++i) s += red[threadIdx.x][i];
-        atomicAdd(dbias + threadIdx.x, s);
+        if (threadIdx.x < Cout)
+            for (int i = 0; i < 256; ++i) s += red[threadIdx.x][i];
+        partial[(long)blockIdx.x * 8 + threadIdx.x] = s;
+    }
+}
+
+// dbias[co] = sum over the rows of partial, in a fixed order: thread t of channel co sums rows t, t + 32, ... and the 32
+// threads' sums are added in lane order
+__global__ void __launch_bounds__(256)
+head_bias_sum_kernel(const float *__restrict__ partial, float *__restrict__ dbias, int rows, int Cout) {
+    __shared__ float red[8][32];
+    const int co = threadIdx.x >> 5, t = threadIdx.x & 31;
+    float s = 0.f;
+    for (int r = t; r < rows; r += 32) s += partial[(long)r * 8 + co];
+    red[co][t] = s;
+    __syncthreads();
+    if (t == 0 && co < Cout) {
+        float a = 0.f;
+        for (int i = 0; i < 32; ++i) a += red[co][i];
+        dbias[co] = a;
     }
 }
 
@@ -221,23 +240,30 @@ extern "C" int ir2rgb_warp_blend_fwd(const float *raw, const float *prev, const 
     return ir2rgb_launch_status();
 }
 
-extern "C" int ir2rgb_head_finish_bwd(const float *gout, const float *out, void *dT, float *dbias, int N, int H, int W,
-                                      int Cout, int KH, int CT, int pad_h, unsigned acts, float mul, int dtype,
+extern "C" int ir2rgb_head_finish_bwd_rows(int N, int H, int W) {
+    if (N < 0 || H < 1 || W < 1) return IR2RGB_EINVAL;
+    return stream_grid((long)N * H * W, 256);
+}
+
+extern "C" int ir2rgb_head_finish_bwd(const float *gout, const float *out, void *dT, float *dbias, float *partial, int N, int H,
+                                      int W, int Cout, int KH, int CT, int pad_h, unsigned acts, float mul, int dtype,
                                       void *stream) {
-    if (N < 0 || H < 2 || W < 1 || Cout < 1 || Cout > 8 || KH < 1 || CT < Cout * KH || (CT & 7) || pad_h < 0 || pad_h >= H)
+    if (N < 0 || H < 2 || W < 1 || Cout < 1 || Cout > 8 || KH < 1 || CT < Cout * KH || (CT & 7) || pad_h < 0 || pad_h >= H || !partial)
         return IR2RGB_EINVAL;
     if (((uintptr_t)dT & 15) != 0) return IR2RGB_EALIGN;
     if (dtype != IR2RGB_BF16 && dtype != IR2RGB_F16) return IR2RGB_ENOSUP;
     long total = (long)N * H * W;
     hipStream_t s = as_stream(stream);
-    hipError_t e = hipMemsetAsync(dbias, 0, sizeof(float) * Cout, s);
-    if (e != hipSuccess) return (int)e;
-    if (total == 0) return IR2RGB_OK;
+    if (total == 0) {
+        hipError_t e = hipMemsetAsync(dbias, 0, sizeof(float) * Cout, s);
+        return e == hipSuccess ? IR2RGB_OK : (int)e;
+    }
     int grid = stream_grid(total, 256);
     if (dtype == IR2RGB_BF16)
-        head_finish_bwd_kernel<IR2RGB_BF16><<<grid, 256, 0, s>>>(gout, out, (uint16_t *)dT, dbias, H, W, Cout, KH, CT, pad_h, acts, mul, total);
+        head_finish_bwd_kernel<IR2RGB_BF16><<<grid, 256, 0, s>>>(gout, out, (uint16_t *)dT, partial, H, W, Cout, KH, CT, pad_h, acts, mul, total);
     else
-        head_finish_bwd_kernel<IR2RGB_F16><<<grid, 256, 0, s>>>(gout, out, (uint16_t *)dT, dbias, H, W, Cout, KH, CT, pad_h, acts, mul, total);
+        head_finish_bwd_kernel<IR2RGB_F16><<<grid, 256, 0, s>>>(gout, out, (uint16_t *)dT, partial, H, W, Cout, KH, CT, pad_h, acts, mul, total);
+    head_bias_sum_kernel<<<1, 256, 0, s>>>(partial, dbias, grid, Cout);
     return ir2rgb_launch_status();
 }
 

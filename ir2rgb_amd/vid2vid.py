@@ -444,10 +444,11 @@ class Vid2VidTrainer:
             m.to(device).train()
             m.compute_dtype = o["compute_dtype"]
         # FlowNet2 is replayed from a HIP graph in every configuration (a capture next to a process group runs in
-        # thread-local mode, FlowNet.compute_flow_and_conf); the SECOND STREAM for the replay is a single-process feature:
-        # with two ranks on one GPU over gloo (bench.py rehearsal) the replay on the second stream next to the collectives
-        # ran 7.6 s per window against 0.43 s on the main stream -- a gloo artefact in all likelihood, but RCCL cannot be run
-        # on the one-GPU development box (IR2RGB_FLOW_STREAM_DP=1 enables the second stream for data-parallel ranks)
+        # thread-local mode, FlowNet.compute_flow_and_conf), on its own stream -- also for data-parallel ranks on RCCL
+        # (tests/test_rccl_gpu.py: bit-identical to the single-process trainer next to RCCL's collectives).  Only the gloo
+        # rehearsal of bench.py keeps it on the main stream: gloo moves CUDA tensors through the host and synchronises
+        # (7.6 s per window measured with the replay on a second stream, 0.43 s on the main one).  IR2RGB_FLOW_STREAM_DP=0/1
+        # overrides.
         self.flow_net = None
         if o["build_flow_net"]:
             self.flow_net = FlowNet(o["flownet_dtype"], use_graph=None).to(device)
@@ -481,8 +482,12 @@ class Vid2VidTrainer:
         import os
         if not t.is_cuda or os.environ.get("IR2RGB_FLOW_STREAM", "1") == "0":
             return None
-        if self.world > 1 and os.environ.get("IR2RGB_FLOW_STREAM_DP", "0") != "1":
-            return None
+        if self.world > 1:
+            dp = os.environ.get("IR2RGB_FLOW_STREAM_DP")
+            if dp is None:
+                dp = "1" if (dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl") else "0"
+            if dp != "1":
+                return None
         if not isinstance(self.flow_net, FlowNet):
             return None
         if getattr(self, "_flow_side", None) is None:
