@@ -99,7 +99,7 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
                      unsigned *tickets = nullptr, float *partials = nullptr) {
     static_assert(SPLIT == 1 || SPLIT == 2, "the hand-over adds two partial tiles (order-independent)");
     typedef P3Cfg<TW, TCO, NCW, NLW, ADJ, SPS, TR> C;
-    static_assert(SPS == 1 || (PIPE && !ADJ), "two slices per step: pipelined forward form only");
+    static_assert(SPS == 1 || (PIPE == 1 && !ADJ), "two slices per step: pipelined forward form only");
     static_assert(TR == 2 || C::PXW == TW, "taller tiles: one pixel row per multiplying wave");
     static_assert(!(ADJ && PIPE) || C::NI <= 2 || C::PXW % TW == 0,
                   "pipelined reflect-adjoint form: border operands must be prefetched (registers: small tile, or whole pixel rows per wave)");
@@ -219,6 +219,7 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
             step(std::integral_constant<int, 2>{});
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (PIPE == 2) __builtin_amdgcn_s_barrier();   // (the multiplying waves' unconditional barrier of the last step)
     } else {
         // =============================== multiplying waves ===============================
         const int wm = wave / C::WN, wn = wave - wm * C::WN;
@@ -239,7 +240,7 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
         // its MFMAs (the fetch is complete: lgkmcnt(0)), so those MFMAs cover the barrier wait and the first
         // fetch of the next step.  (With the barrier at the top of a step every wave of the CU idled through
         // its first LDS round trip: MFMA-busy 58 %.)
-        frag fa[PIPE ? 2 : 1][MI], fb[PIPE ? 2 : 1][NI];
+        frag fa[PIPE ? 2 : 1][MI], fb[PIPE == 1 ? 2 : 1][NI];
         auto fetch = [&](int buf, const unsigned char *wst, const unsigned char *patch, int kyoff, int kx) {
             if (g.dbg & 2) return;
 #pragma unroll
@@ -314,7 +315,7 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
                 if (rowterm && kx == 0 && right && tx == TW - 16) term(PRE ? eb_row[2][ni * pi] : entry(patch, ni, rowoff, 2), 14);
             }
         };
-        if constexpr (PIPE && SPS == 2) {
+        if constexpr (PIPE == 1 && SPS == 2) {
             // a step = one ky of a whole 64-channel chunk: six taps (slice, kx); tap t lives in fragment buffer t & 1,
             // the barrier that opens the next step sits before the MFMAs of the last tap (see below)
             int ks = 0;
@@ -349,6 +350,95 @@ conv3x3_patch_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict_
                 step(std::integral_constant<int, 0>{});
                 step(std::integral_constant<int, 1>{});
                 step(std::integral_constant<int, 2>{});
+            }
+        } else if constexpr (PIPE == 2) {
+            // Large tile (NI = 4, two multiplying waves per SIMD, 168 registers): the full pipelined form below needs two
+            // complete fragment sets (+32 registers: spills).  Here only the weight fragments are double-buffered (+16);
+            // the pixel fragments are refilled column by column -- fb[ni] is reloaded for the NEXT tap right after the four
+            // MFMAs that read it -- so the next tap's operands arrive while the current tap multiplies, within one set.
+            // The barrier that opens step ks+1 sits in front of the last tap's MFMAs (its fragments are complete:
+            // lgkmcnt(0), which is also what makes handing the stage back safe), and that tap refills from step ks+1.
+            static_assert(!ADJ && SPS == 1, "column-refill form: forward, one slice per step");
+            // The reads are inline asm and the waits are counted by hand: left to hipcc, the reads sink down to their uses
+            // (it schedules for register pressure at this occupancy) and every MFMA group ends up behind a full
+            // s_waitcnt of the read issued just before it.  A wait names the fragments it makes valid ("+v"), so the MFMAs
+            // that read them cannot be scheduled above it; __builtin_amdgcn_sched_barrier(0) keeps the groups in order.
+            // Addresses are a per-lane base register + a compile-time immediate (the weight stage of a step is its ky:
+            // six steps per 64-channel chunk, three stages); the third stage lies beyond the 16-bit immediate's reach and
+            // has base registers of its own.
+            static_assert(C::NSTW == 3 && C::PBUF + 2 * 64 + 2 * C::PWP * 64 < 65536 && C::WST + 2 * TCO * 64 < 65536, "immediates");
+            const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char *)smem;
+            unsigned abase[2][MI], bbase[3][NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) { abase[0][mi] = lds0 + aofs[mi]; abase[1][mi] = lds0 + aofs[mi] + 2 * C::WST; }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                bbase[0][ni] = lds0 + C::NSTW * C::WST + bofs[ni];
+                bbase[1][ni] = lds0 + C::NSTW * C::WST + (bofs[ni] ^ flip1);
+                bbase[2][ni] = lds0 + C::NSTW * C::WST + (bofs[ni] ^ flip2);
+            }
+            auto rd = [&]<int IMM>(frag &dst, unsigned addr, std::integral_constant<int, IMM>) {
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM) : "memory");
+            };
+            // operands of tap (stage ST, column kx; patch buffer HB, row offset ky): weights -> fa[buf], one pixel column -> fb[0][ni]
+            auto fetchA = [&]<int ST, int KX>(int buf, std::integral_constant<int, ST>, std::integral_constant<int, KX>) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    rd(fa[buf][mi], abase[ST == 2][mi], std::integral_constant<int, (ST == 2 ? 0 : ST * C::WST) + KX * TCO * 64>{});
+            };
+            auto fetchB = [&]<int HB, int KYR, int KX>(int ni, std::integral_constant<int, HB>, std::integral_constant<int, KYR>,
+                                                       std::integral_constant<int, KX>) {
+                rd(fb[0][ni], bbase[KX][ni], std::integral_constant<int, HB * C::PBUF + KX * 64 + KYR * C::PWP * 64>{});
+            };
+            // one tap: weights in fa[cur], pixels in fb[0]; meanwhile the next tap's weights go to fa[cur ^ 1] and its pixel
+            // fragments replace fb[0] column by column.  LDS operations in flight, oldest first, when column ni is due:
+            // [this tap's operands up to fb[ni]] fb[ni+1..3] | the four fa[cur ^ 1] reads | the refills fb[0..ni-1]: seven
+            // younger ones in every column, so the wait is lgkmcnt(7) throughout (after the step's lgkmcnt(0): a no-op).
+            // (no condition around the fetches or the barrier: with a branch in the loop hipcc's s_waitcnt insertion merges
+            // the two paths' LDS scoreboards; the last step therefore fetches a tap nobody multiplies, from stages that
+            // exist, and the staging waves run one barrier more to match.)
+            auto tap = [&]<int ST, int HB, int KYR, int KX>(int cur, std::integral_constant<int, ST> st, std::integral_constant<int, HB> hb,
+                                                             std::integral_constant<int, KYR> kyr, std::integral_constant<int, KX> kx) {
+                fetchA(cur ^ 1, st, kx);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    if (ni == 0)
+                        asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(fa[cur][0]), "+v"(fa[cur][1]), "+v"(fa[cur][2]), "+v"(fa[cur][3]), "+v"(fb[0][0]) :: "memory");
+                    else
+                        asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(fb[0][ni]) :: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = Hf::mfma(fa[cur][mi], fb[0][ni], acc[mi][ni]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    fetchB(ni, hb, kyr, kx);
+                }
+            };
+            using I0 = std::integral_constant<int, 0>;
+            using I1 = std::integral_constant<int, 1>;
+            using I2 = std::integral_constant<int, 2>;
+            __builtin_amdgcn_s_barrier();                       // step 0 has landed
+            fetchA(0, I0{}, I0{});
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) fetchB(ni, I0{}, I0{}, I0{});
+            for (int cc = 0; cc < kcl; ++cc) {
+                // step (ky = KY of slice HALF): weight stage KY, patch buffer HALF; P = fragment set of its first tap
+                auto step = [&]<int KY, int P, int HALF>(std::integral_constant<int, KY> ky, std::integral_constant<int, P>,
+                                                         std::integral_constant<int, HALF> half) {
+                    tap(P, ky, half, ky, I1{});                  // tap kx = 0; fetches kx = 1
+                    tap(P ^ 1, ky, half, ky, I2{});              // tap kx = 1; fetches kx = 2
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read of this step is complete
+                    __builtin_amdgcn_s_barrier();                // the next step has landed; this step's stage may be overwritten
+                    __builtin_amdgcn_sched_barrier(0);
+                    // tap kx = 2; fetches tap 0 of the next step: next ky of this slice, or ky = 0 of the next slice
+                    if constexpr (KY < 2) tap(P, std::integral_constant<int, KY + 1>{}, half, std::integral_constant<int, KY + 1>{}, I0{});
+                    else tap(P, I0{}, std::integral_constant<int, HALF ^ 1>{}, I0{}, I0{});
+                };
+                step(I0{}, I0{}, I0{});
+                step(I1{}, I1{}, I0{});
+                step(I2{}, I0{}, I0{});
+                step(I0{}, I1{}, I1{});
+                step(I1{}, I0{}, I1{});
+                step(I2{}, I1{}, I1{});
             }
         } else if constexpr (PIPE) {
             int ks = 0;
@@ -721,10 +811,18 @@ int conv3x3p_launch(int variant, const P3Geom &g, int dtype, const void *x, cons
             if (dtype == IR2RGB_BF16) conv3x3_patch_kernel<IR2RGB_BF16, 128, 128, 8, 4, 0, 1, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
             else conv3x3_patch_kernel<IR2RGB_F16, 128, 128, 8, 4, 0, 1, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
         } else {
-            // (the pipelined form at this tile needs 2 x (MI + NI) fragment registers more than the 168 the 12-wave
-            // workgroup leaves a wave: measured in round 2, 8 VGPRs spilled -- the plain form stays)
-            if (dtype == IR2RGB_BF16) conv3x3_patch_kernel<IR2RGB_BF16, 128, 128, 8, 4, 0, 0, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
-            else conv3x3_patch_kernel<IR2RGB_F16, 128, 128, 8, 4, 0, 0, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+            // (the fully pipelined form at this tile needs 2 x (MI + NI) fragment registers more than the 168 the 12-wave
+            // workgroup leaves a wave: measured in round 2, 8 VGPRs spilled.  PIPE = 2, round 3: weights double-buffered,
+            // pixel fragments refilled column by column; IR2RGB_CONV3X3P_LARGE_PIPE=0 selects the plain loop for A/B runs)
+            static int lp = -1;
+            if (lp < 0) { const char *e = getenv("IR2RGB_CONV3X3P_LARGE_PIPE"); lp = e ? atoi(e) : 1; }
+            if (lp) {
+                if (dtype == IR2RGB_BF16) conv3x3_patch_kernel<IR2RGB_BF16, 128, 128, 8, 4, 2, 0, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+                else conv3x3_patch_kernel<IR2RGB_F16, 128, 128, 8, 4, 2, 0, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+            } else {
+                if (dtype == IR2RGB_BF16) conv3x3_patch_kernel<IR2RGB_BF16, 128, 128, 8, 4, 0, 0, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+                else conv3x3_patch_kernel<IR2RGB_F16, 128, 128, 8, 4, 0, 0, 1><<<grid, 768, 0, s>>>(X, W, bias, Yp, stats, g);
+            }
         }
     } else {
         const unsigned grid = (unsigned)(npt * (g.Cout / 64));

@@ -34,6 +34,7 @@
 #include <utility>
 
 #include "common.h"
+#include "conv1x7_thin.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
@@ -942,6 +943,10 @@ extern "C" const char *ir2rgb_conv2d_kernel_name(const ir2rgb_conv_desc *d) {
     P3Geom g3;
     int npt3 = 0;
     if (conv3x3p_plan(d, &g3, &npt3)) return "conv3x3_patch_kernel";
+    {
+        T7Geom g7;
+        if (conv1x7_thin_plan(d, &g7)) return "conv1x7_thin_kernel";     // (launches without bias / statistics: the head pass)
+    }
     ClassPlan plans[4];
     const int n = make_plan(d, plans);
     if (n < 0) return "";
@@ -1180,6 +1185,10 @@ extern "C" int ir2rgb_conv2d_fwd_ws(const ir2rgb_conv_desc *d, const void *x, co
                                     void *y, float *stats_partial, void *workspace, long workspace_bytes, void *stream) {
     if (!d) return IR2RGB_EINVAL;
     if ((((uintptr_t)x | (uintptr_t)wpacked | (uintptr_t)y) & 15) != 0) return IR2RGB_EALIGN;
+    if (bias == nullptr && stats_partial == nullptr) {
+        T7Geom g7;      // the 1x7 pass of the separable heads: row-segment staging, weights in registers (conv1x7_thin.hip)
+        if (conv1x7_thin_plan(d, &g7)) return conv1x7_thin_launch(g7, d->dtype, d->Cin, x, wpacked, y, as_stream(stream));
+    }
     {
         P3Geom g3;
         int npt3 = 0;

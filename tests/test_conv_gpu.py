@@ -258,3 +258,33 @@ def test_full_size_adjoint_identities(dev):
     # y and dx are rounded to bf16 (2^-9 relative per element, random signs over 2M terms); dw is fp32
     assert abs(a - c) <= 2e-4 * scale, (a, c, scale)
     assert abs(b - c) <= 2e-4 * scale, (b, c, scale)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,Cin,H,W,Cout", [(1, 128, 9, 300, 24), (2, 64, 5, 129, 24), (1, 128, 3, 70, 21), (1, 64, 4, 1024, 24),
+                                            (1, 128, 2, 5, 24)])
+def test_head_1x7_pass_row_segment_kernel(dev, dtype, N, Cin, H, W, Cout):
+    """conv1x7_thin_kernel (the 1x7 pass of the separable heads, reference networks.py:165-171 as layers.head_stage
+    evaluates them: reflection pad 3, Cout*7 <= 24 fp32 row responses, no bias): against torch's fp32 convolution on the
+    same half-rounded operands -- ragged widths (last segment mostly empty, images narrower than a segment), both channel
+    counts, a Cout that is not a multiple of 4, operands inside NaN guard bands and the output inside canary bands."""
+    from ir2rgb_amd import conv as C
+    from test_bounds_gpu import Guarded
+    g = torch.Generator(device="cpu").manual_seed(Cin + W)
+    x = torch.randn(N, Cin, H, W, generator=g).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, 1, 7, generator=g) * (1.0 / np.sqrt(Cin * 7))).to(dev)
+    desc = C.make_desc(tuple(x.shape), Cout, (1, 7), 1, (0, 3), C.PAD_REFLECT, dtype, out_f32=True)
+    wp = C.pack_weight(desc, w)
+    if Cout % 4 == 0:
+        assert C.kernel_name(desc) == "conv1x7_thin_kernel"
+    gx, gw = Guarded(x, float("nan")), Guarded(wp, float("nan"))
+    y0, _ = C.conv2d_fwd(desc, x, wp)
+    gy = Guarded(y0, 7.0)
+    gy.t.zero_()
+    y1, _ = C.conv2d_fwd(desc, gx.t, gw.t, out=gy.t)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y0) and gy.intact() and gx.intact() and gw.intact()
+    ref = F.conv2d(F.pad(x.float(), (3, 3, 0, 0), mode="reflect"), w.to(dtype).float())
+    assert y0.dtype == torch.float32 and y0.shape == ref.shape
+    rms = ref.pow(2).mean().sqrt().item()
+    assert ((y0 - ref).abs() <= 1e-5 * ref.abs() + 2e-4 * rms).all(), (y0 - ref).abs().max().item()

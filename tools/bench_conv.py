@@ -18,7 +18,7 @@ SHAPES = [  # name, Cin, H, W, Cout, k, stride, pad, pad_mode, transposed, opad
 def main():
     dev = torch.device("cuda:0")
     dt = torch.bfloat16 if "--f16" not in sys.argv else torch.float16
-    iters = 20
+    iters = int(os.environ.get("ITERS", "100"))
     for name, cin, h, w, cout, k, s, p, pm, tr, op in SHAPES:
         x = torch.randn(1, cin, h, w, device=dev).to(dt).contiguous(memory_format=torch.channels_last)
         wt = torch.randn((cin, cout, k, k) if tr else (cout, cin, k, k), device=dev) * 0.02
