@@ -375,7 +375,7 @@ int ir2rgb_flow_upsample_slice(const float *in, const float *weight, const float
  * in block order).  ga, when not NULL, receives d out[slot] / d a scaled by gout[slot] (same dtype
  * and layout as a).
  * ------------------------------------------------------------------------------------------ */
-#define IR2RGB_LOSS_MAX_ITEMS 16
+#define IR2RGB_LOSS_MAX_ITEMS 32
 typedef struct ir2rgb_loss_item {
     const void *a;
     const void *b;

@@ -24,7 +24,7 @@ class ConvDesc(ctypes.Structure):
 
 _pdesc = ctypes.POINTER(ConvDesc)
 
-LOSS_MAX_ITEMS = 16
+LOSS_MAX_ITEMS = 32
 
 
 class LossItem(ctypes.Structure):

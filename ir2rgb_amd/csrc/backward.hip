@@ -400,6 +400,117 @@ static int bn_bwd_ranges(long npix, int C) {
     return (int)(want < cap ? want : cap);
 }
 
+// ----------------------------------------------------------------------------------------
+// BatchNorm backward in ONE launch for layers with few pixels (the 1024-channel residual blocks at 32x64, the deep
+// discriminator layers: half of the BatchNorm layers of a training window).  The two-launch form above needs the
+// per-channel sums of the WHOLE tensor before any gradient can be written, i.e. a kernel boundary between reduce and
+// apply; each of the two launches then costs ~13 us of dependent latency on tensors of a few MB.  Here a workgroup owns a
+// group of CPB channels over ALL pixels: its slab of gz and y (P x CPB halfs each) fits the registers of 512 threads
+// (K 16-byte loads per tensor and thread, all in flight at once; 512 threads leave a thread 256 registers -- at 1024 the
+// 128-register cap spilled from K = 4 on, and scratch costs dispatch latency), so it sums, derives the coefficients and
+// applies them without the tensors leaving the CU -- one read of gz and y, one write of gy, no partial rows, no second launch.
+//   thread t: channel octet t % (CPB/8), pixels t / (CPB/8) + k * (512 / (CPB/8)), k < K
+// Sums: per thread in fp32, across the lanes of a wave by shuffles, across the 8 waves in wave order in double.
+// ----------------------------------------------------------------------------------------
+template <int K, int CPB>
+__global__ void __launch_bounds__(512)
+bn_bwd_onepass_kernel(const uint4 *__restrict__ gz, const uint4 *__restrict__ y, const float *__restrict__ scale,
+                      const float *__restrict__ shift, const float *__restrict__ mean, const float *__restrict__ invstd,
+                      uint4 *__restrict__ gy, float *__restrict__ dgamma, float *__restrict__ dbeta, long npix, int C, int act,
+                      int dt, float inv_n, int acc) {
+    constexpr int LPP = CPB / 8;                 // lanes per pixel
+    constexpr int PPP = 512 / LPP;               // pixels per pass
+    __shared__ double red[2][8][CPB];
+    __shared__ float co[3][CPB];
+    const int t = threadIdx.x, oc = t % LPP, prow = t / LPP, wave = t >> 6, lane = t & 63;
+    const int c0 = blockIdx.x * CPB + oc * 8, C8 = C >> 3;
+    const long cidx = (long)blockIdx.x * LPP + oc;
+    uint4 gq[K], yq[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {                // unconditional loads from a clamped pixel, masked below (a predicated
+        const long p = (long)prow + (long)k * PPP;   // load compiles to a branch with its own wait: K serial round trips)
+        const long q = p < npix ? p : npix - 1;
+        gq[k] = gz[q * C8 + cidx];
+        yq[k] = y[q * C8 + cidx];
+    }
+    float sc[8], sh[8], mu[8], is[8], s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j]; s1[j] = s2[j] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const bool ok = (long)prow + (long)k * PPP < npix;
+        float g[8], v[8];
+        unpack8(gq[k], g, dt);
+        unpack8(yq[k], v, dt);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float gp = ok ? act_grad(g[j], v[j] * sc[j] + sh[j], act) : 0.f;
+            s1[j] += gp;
+            s2[j] += gp * (v[j] - mu[j]) * is[j];
+        }
+        __builtin_amdgcn_sched_barrier(0);       // (one load's 16 unpacked values at a time: the slab itself stays packed)
+    }
+    // lanes of a wave that hold the same channel octet: lane bits log2(LPP) .. 5
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int m = LPP; m < 64; m <<= 1) {
+            s1[j] += __shfl_xor(s1[j], m);
+            s2[j] += __shfl_xor(s2[j], m);
+        }
+    }
+    if (lane < LPP) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { red[0][wave][lane * 8 + j] = (double)s1[j]; red[1][wave][lane * 8 + j] = (double)s2[j]; }
+    }
+    __syncthreads();
+    if (t < CPB) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { a += red[0][w][t]; b += red[1][w][t]; }
+        const int c = blockIdx.x * CPB + t;
+        const float scv = scale[c], isv = invstd[c], muv = mean[c];
+        const float dg = (float)b * inv_n, db = (float)a * inv_n;
+        co[0][t] = scv;
+        co[1][t] = -scv * isv * dg;
+        co[2][t] = scv * (isv * muv * dg - db);
+        dbeta[c] = (acc ? dbeta[c] : 0.f) + (float)a;
+        dgamma[c] = (acc ? dgamma[c] : 0.f) + (float)b;
+    }
+    __syncthreads();
+    float cA[8], cB[8], cC[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { cA[j] = co[0][oc * 8 + j]; cB[j] = co[1][oc * 8 + j]; cC[j] = co[2][oc * 8 + j]; }
+    // (the slab stays PACKED between the two passes: without this the compiler keeps the 16 unpacked floats of every
+    // load alive across the reduction -- 238 registers at K = 8, scratch beyond)
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        asm volatile("" : "+v"(gq[k].x), "+v"(gq[k].y), "+v"(gq[k].z), "+v"(gq[k].w), "+v"(yq[k].x), "+v"(yq[k].y), "+v"(yq[k].z), "+v"(yq[k].w));
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const long p = (long)prow + (long)k * PPP;
+        float g[8], v[8], o[8];
+        unpack8(gq[k], g, dt);
+        unpack8(yq[k], v, dt);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = cA[j] * act_grad(g[j], v[j] * sc[j] + sh[j], act) + cB[j] * v[j] + cC[j];
+        if (p < npix) gy[p * C8 + cidx] = pack8(o, dt);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int CPB>
+static bool bn_bwd_onepass_launch(int K, dim3 grid, hipStream_t s, const uint4 *gz, const uint4 *y, const float *scale,
+                                  const float *shift, const float *mean, const float *invstd, uint4 *gy, float *dgamma,
+                                  float *dbeta, long npix, int C, int act, int dt, float inv_n, int acc) {
+#define IR2RGB_ONEPASS(KK) bn_bwd_onepass_kernel<KK, CPB><<<grid, 512, 0, s>>>(gz, y, scale, shift, mean, invstd, gy, dgamma, dbeta, npix, C, act, dt, inv_n, acc)
+    if (K <= 4) IR2RGB_ONEPASS(4);
+    else if (K <= 8) IR2RGB_ONEPASS(8);       // (K = 12 would need scratch: 256 registers are gone at K = 9)
+    else return false;
+#undef IR2RGB_ONEPASS
+    return true;
+}
+
 extern "C" int ir2rgb_bn_bwd_blocks(long npix, int C) {
     if (npix < 1 || C < 64 || (C & (C - 1)) || C > 2048) return IR2RGB_EINVAL;
     const int R = bn_bwd_ranges(npix, C);
@@ -420,6 +531,30 @@ extern "C" int ir2rgb_bn_bwd(const void *gz, const void *y, const float *scale, 
     const int R0 = bn_bwd_ranges(npix, C);
     const long per = (npix + R0 - 1) / R0;
     hipStream_t s = as_stream(stream);
+    // few pixels per channel: the one-launch form (a workgroup owns CPB channels over all pixels, slabs in registers).
+    // 8 channels per workgroup while that gives at most 8 loads per tensor and thread, else not applicable; wider
+    // groups (better coalescing, fewer workgroups) when the layer still yields >= 128 workgroups.
+    {
+        static int onepass = -1;
+        if (onepass < 0) { const char *e = getenv("IR2RGB_BN_BWD_ONEPASS"); onepass = e ? atoi(e) : 1; }
+        if (onepass && scale && shift && mean && invstd && !frozen && npix <= 8 * 512) {
+            const float inv_n = 1.0f / (float)npix;
+            bool done;
+            static int force_cpb = -1;      // IR2RGB_BN_BWD_ONEPASS_CPB=8|16|32: A/B measurements
+            if (force_cpb < 0) { const char *e = getenv("IR2RGB_BN_BWD_ONEPASS_CPB"); force_cpb = e ? atoi(e) : 0; }
+            const int min_wg = force_cpb ? 1 : 128;
+            if ((!force_cpb || force_cpb == 32) && C / 32 >= min_wg && npix * 4 <= 8 * 512)
+                done = bn_bwd_onepass_launch<32>((int)((npix * 4 + 511) / 512), dim3(C / 32), s, (const uint4 *)gz, (const uint4 *)y, scale, shift,
+                                                 mean, invstd, (uint4 *)gy, dgamma, dbeta, npix, C, act, dtype, inv_n, acc);
+            else if ((!force_cpb || force_cpb == 16) && C / 16 >= min_wg && npix * 2 <= 8 * 512)
+                done = bn_bwd_onepass_launch<16>((int)((npix * 2 + 511) / 512), dim3(C / 16), s, (const uint4 *)gz, (const uint4 *)y, scale, shift,
+                                                 mean, invstd, (uint4 *)gy, dgamma, dbeta, npix, C, act, dtype, inv_n, acc);
+            else
+                done = bn_bwd_onepass_launch<8>((int)((npix + 511) / 512), dim3(C / 8), s, (const uint4 *)gz, (const uint4 *)y, scale, shift,
+                                                mean, invstd, (uint4 *)gy, dgamma, dbeta, npix, C, act, dtype, inv_n, acc);
+            if (done) return ir2rgb_launch_status();
+        }
+    }
     // partial holds R*2*C floats followed by 3*C coefficient floats (see ir2rgb_hip.h)
     float *coef = partial + (long)R * 2 * C;
     bn_bwd_reduce_kernel<<<R * (C / 64), 512, 0, s>>>((const uint4 *)gz, (const uint4 *)y, scale, shift, mean, invstd,

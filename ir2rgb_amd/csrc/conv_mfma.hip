@@ -887,6 +887,14 @@ static int make_plan(const ir2rgb_conv_desc *d, ClassPlan plans[4]) {
             ks_sum += (long)g.kchunks * g.ntaps;
         }
         tp_all = tile_pixels(p_all, plans[0].geom.Cout, (int)(ks_sum / ncls));     // mean K steps over the classes
+        // Classes have K loops of different lengths (3x3 / stride 2: 1, 2, 2 and 4 taps) and a workgroup keeps its class
+        // to the end: with 128-pixel tiles and at most ~one round of workgroups (the training sizes: 1024 -> 512 @32x64
+        // has 256 of them) every CU runs ONE workgroup and the launch lasts as long as the 4-tap class.  64-pixel tiles give
+        // two co-resident workgroups per CU, long and short ones mixed.  IR2RGB_CONV_CLASSES_SMALL=0: the earlier rule.
+        static int small = -1;
+        if (small < 0) { const char *e = getenv("IR2RGB_CONV_CLASSES_SMALL"); small = e ? atoi(e) : 1; }
+        const long wg128 = ((p_all + 127) / 128) * ((plans[0].geom.Cout + 127) / 128);
+        if (small && tp_all == 128 && wg128 <= 320) tp_all = 64;
     }
     for (int i = 0; i < ncls; ++i) {
         ConvGeom &g = plans[i].geom;

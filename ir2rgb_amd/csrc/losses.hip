@@ -3,7 +3,7 @@
 // The reference evaluates every discriminator-feature L1 term and every least-squares GAN term as its
 // own chain of torch elementwise + reduction kernels (models/networks.py GANLoss, discriminator.py
 // compute_loss_D: criterionFeat / criterionGAN) -- ~10 tensor passes and ~10 launches per term
-// forward + backward.  Here a group of up to 16 terms is one kernel: every block owns a contiguous
+// forward + backward.  Here a group of up to 32 terms is one kernel: every block owns a contiguous
 // range of one term, sums it in fp32 and writes one partial; a second tiny kernel adds the partials
 // in block order (deterministic) into up to 4 output scalars.  The backward is one launch as well.
 //

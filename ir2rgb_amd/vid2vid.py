@@ -549,21 +549,15 @@ class Vid2VidTrainer:
                     weights.append(weight.unsqueeze(1))
         self.fake_B_prev = [B[:, -tG + 1:].detach() for B in fake_pyr]
         fake_B = fake_pyr[0][:, tG - 1:]
-        return (fake_B, torch.cat(fake_raw, 1), torch.cat(flows, 1), torch.cat(weights, 1), real_A_all[:, tG - 1:],
-                real_B_all[:, tG - 2:])
+        one = lambda ts: ts[0] if len(ts) == 1 else torch.cat(ts, 1)  # noqa: E731  (one frame per window: no copy)
+        return (fake_B, one(fake_raw), one(flows), one(weights), real_A_all[:, tG - 1:], real_B_all[:, tG - 2:])
 
     # ------------------------------------------------------------------ discriminator losses (a13)
     def _gan_and_fm(self, pred_real, pred_fake):
         o = self.opt
         fw, dw = 4.0 / (o["n_layers_D"] + 1), 1.0 / o["num_D"]
         if o["fused_losses"]:
-            terms = [("mse", scale[-1], 1.0, 1.0, 0) for scale in pred_fake]
-            if not o["no_ganFeat"]:
-                for i in range(min(len(pred_fake), o["num_D"])):
-                    for j in range(len(pred_fake[i]) - 1):
-                        terms.append(("l1", pred_fake[i][j], pred_real[i][j], dw * fw * o["lambda_feat"], 1))
-            out = fused_losses(terms, 2, o["compute_dtype"])
-            return out[0], out[1]
+            return self._fused_D_terms(pred_real, [pred_fake])[1].unbind(0)
         loss_gan = gan_loss(pred_fake, True)
         loss_fm = torch.zeros_like(loss_gan)
         if not o["no_ganFeat"]:
@@ -571,6 +565,27 @@ class Vid2VidTrainer:
                 for j in range(len(pred_fake[i]) - 1):
                     loss_fm = loss_fm + dw * fw * (pred_fake[i][j] - pred_real[i][j].detach()).abs().mean(dtype=torch.float32) * o["lambda_feat"]
         return loss_gan, loss_fm
+
+    def _fused_D_terms(self, pred_real, pred_fakes):
+        """compute_loss_D (discriminator.py:154-166, :186-200) for every generated input in ``pred_fakes`` against the same
+        real forward, as TWO loss launches: the discriminator-side vector [D_real, D_fake] and the generator-side vector
+        [G_GAN, G_GAN_Feat], each already summed over the inputs.  (Two groups, not one: a backward pass then differentiates
+        only the group its total depends on, and every prediction tensor receives one gradient per pass.)  The real
+        logits appear in one term of weight len(pred_fakes): the reference evaluates that term once per compute_loss_D call
+        on identical activations -- two terms on one tensor would write one gradient destination twice (losses.GRAD_DST)."""
+        o = self.opt
+        fw, dw = 4.0 / (o["n_layers_D"] + 1), 1.0 / o["num_D"]
+        k = float(len(pred_fakes))
+        d_terms = [("mse", scale[-1], 1.0, k, 0) for scale in pred_real]
+        g_terms = []
+        for pf in pred_fakes:
+            d_terms += [("mse", scale[-1], 0.0, 1.0, 1) for scale in pf]
+            g_terms += [("mse", scale[-1], 1.0, 1.0, 0) for scale in pf]
+            if not o["no_ganFeat"]:
+                for i in range(min(len(pf), o["num_D"])):
+                    for j in range(len(pf[i]) - 1):
+                        g_terms.append(("l1", pf[i][j], pred_real[i][j], dw * fw * o["lambda_feat"], 1))
+        return fused_losses(d_terms, 2, o["compute_dtype"]), fused_losses(g_terms, 2, o["compute_dtype"])
 
     def _loss_D(self, netD, real_in, fake_in, pred_real=None, pred_fake=None):
         """Three forwards exactly as compute_loss_D (discriminator.py:154-166).  ``pred_real`` / ``pred_fake``: the results
@@ -585,6 +600,9 @@ class Vid2VidTrainer:
                 pred_fake_d = pred_fake = netD(fake_in)
         else:
             pred_fake_d = netD(fake_in.detach())
+        if self.opt["fused_losses"] and pred_fake is not None:
+            dvec, gvec = self._fused_D_terms(pred_real, [pred_fake])
+            return tuple(dvec.unbind(0)) + tuple(gvec.unbind(0))
         if self.opt["fused_losses"]:
             out = fused_losses([("mse", scale[-1], 1.0, 1.0, 0) for scale in pred_real] +
                                [("mse", scale[-1], 0.0, 1.0, 1) for scale in pred_fake_d], 2, self.opt["compute_dtype"])
@@ -627,14 +645,15 @@ class Vid2VidTrainer:
         o = self.opt
         L = {}
         wF, wT = o["lambda_F"] / (2 ** (self.n_scales - 1)), o["lambda_T"]
+        imgvec = None
         if o["fused_losses"]:
             terms = [("ml1", flow, flow_ref, conf_ref, wF, 0),
                      ("ml1", resample(real_B_prev, flow), real_B, conf_ref, wT, 1),
                      ("ml1", fake_B, resample(fake_B_prev, flow_ref), conf_ref, wT, 3)]
             if o["no_first_img"]:
                 terms.append(("ml1", weight, None, conf_ref, 1.0, 2))
-            out = fused_losses(terms, 4, o["compute_dtype"])
-            L["F_Flow"], L["F_Warp"], L["W"], L["G_Warp"] = out[0], out[1], out[2], out[3]
+            imgvec = fused_losses(terms, 4, o["compute_dtype"])
+            L["F_Flow"], L["F_Warp"], L["W"], L["G_Warp"] = imgvec.unbind(0)
         else:
             L["F_Flow"] = masked_l1(flow, flow_ref, conf_ref) * wF
             L["F_Warp"] = masked_l1(resample(real_B_prev, flow), real_B, conf_ref) * wT
@@ -656,6 +675,13 @@ class Vid2VidTrainer:
             with layers.repeated_forward(2):
                 pred_real = self.netD(real_in)
             pred_fake = pred_raw = None
+        if o["fused_losses"] and pred_fake is not None:
+            # both compute_loss_D calls in two launches; the sums D_real + D_real2 ... are formed inside the kernels
+            dvec, gvec = self._fused_D_terms(pred_real, [pred_fake, pred_raw])
+            L["D_real"], L["D_fake"] = dvec.unbind(0)
+            L["G_GAN"], L["G_GAN_Feat"] = gvec.unbind(0)
+            self._loss_vecs = {id(L): (imgvec, dvec, gvec)}
+            return L
         d_real, d_fake, g_gan, g_fm = self._loss_D(self.netD, real_in, fake_in, pred_real, pred_fake)
         d_real2, d_fake2, g_gan2, g_fm2 = self._loss_D(self.netD, real_in, raw_in, pred_real, pred_raw)
         L["D_real"], L["D_fake"] = d_real + d_real2, d_fake + d_fake2
@@ -671,6 +697,11 @@ class Vid2VidTrainer:
         fake_in = torch.cat([fake_B.reshape(b, -1, h, w), fl], 1)
         if self.opt["batched_D"] and self.opt["shared_fake_forward"]:
             pred_fake, pred_real = self._batched_D(self.netD_T[s], [fake_in, real_in], (2, 1), (1, 0))
+            if self.opt["fused_losses"]:
+                dvec, gvec = self._fused_D_terms(pred_real, [pred_fake])
+                LT = dict(zip(("D_T_real", "D_T_fake", "G_T_GAN", "G_T_GAN_Feat"), tuple(dvec.unbind(0)) + tuple(gvec.unbind(0))))
+                self.__dict__.setdefault("_loss_vecs", {})[id(LT)] = (None, dvec, gvec)
+                return LT
             d_real, d_fake, g_gan, g_fm = self._loss_D(self.netD_T[s], real_in, fake_in, pred_real, pred_fake)
         else:
             d_real, d_fake, g_gan, g_fm = self._loss_D(self.netD_T[s], real_in, fake_in)
@@ -803,7 +834,20 @@ class Vid2VidTrainer:
     # ------------------------------------------------------------------ the loop body (a14)
     def get_losses(self, L, LT):
         """Vid2VidModelD.get_losses (discriminator.py:236-248): ``L`` the image-loss dict, ``LT`` the list of temporal
-        dicts of the active temporal scales.  Returns (loss_G, loss_D, [loss_D_T per active scale])."""
+        dicts of the active temporal scales.  Returns (loss_G, loss_D, [loss_D_T per active scale]).
+        Dicts that came out of the fused loss kernels carry their terms as vectors (``_loss_vecs``, keyed by dict identity):
+        the totals are then one concatenation + one sum for loss_G and one sum per discriminator -- not ~45 scalar adds
+        forward and as many select / add nodes backward."""
+        vecs = getattr(self, "_loss_vecs", {})
+        mine = [vecs.get(id(d)) for d in [L] + list(LT)]
+        if all(v is not None for v in mine) and mine[0][0] is not None:
+            imgvec, dvec, gvec = mine[0]
+            g_parts = [imgvec, gvec] + [m[2] for m in mine[1:]]
+            loss_G = torch.cat(g_parts).sum()
+            if not self.opt["no_vgg"]:
+                loss_G = loss_G + L["G_VGG"]
+            loss_D = dvec.sum() * 0.5
+            return loss_G, loss_D, [m[1].sum() * 0.5 for m in mine[1:]]
         loss_D = (L["D_fake"] + L["D_real"]) * 0.5
         loss_G = L["G_GAN"] + L["G_GAN_Feat"] + L["G_VGG"] + L["G_Warp"] + L["F_Flow"] + L["F_Warp"] + L["W"]
         loss_D_T = []

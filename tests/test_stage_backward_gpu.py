@@ -262,3 +262,34 @@ def test_head_and_warp_blend_backward(dev, dtype, tol):
         errs[f"db_{name}"] = _rel(cv.bias.grad, gb)
     bad = {k: v for k, v in errs.items() if not v <= tol}
     assert not bad, errs
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.5e-2)])
+@pytest.mark.parametrize("C,H,W,act", [(1024, 32, 64, 1), (512, 61, 67, 2), (256, 33, 65, 2), (64, 3, 5, 1), (128, 64, 64, 1), (2048, 4, 8, 0)])
+def test_bn_backward_kernels_vs_autograd(dev, dtype, tol, C, H, W, act):
+    """ir2rgb_bn_bwd against torch autograd of act(batch_norm(y)) in fp32 on the same half-rounded y and gz: the one-launch
+    form (a workgroup owns 8-32 channels over all pixels, slabs in registers: every case here with <= 4096 pixels,
+    K = 4 and K = 8 variants, all three channel-group widths) and the two-launch form (128 x 64x64), plus the in-kernel
+    accumulation of dgamma / dbeta over a second call (sample groups)."""
+    from ir2rgb_amd import autograd as A
+    from ir2rgb_amd import layers as L
+    g = torch.Generator().manual_seed(C + H)
+    y = (torch.randn(1, C, H, W, generator=g) * 1.5 + 0.3).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    gz = torch.randn(1, C, H, W, generator=g).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).to(dev), (0.2 * torch.randn(C, generator=g)).to(dev)
+    yr = y.float().contiguous().detach().requires_grad_()
+    gr, br = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    with torch.backends.cudnn.flags(enabled=False):      # (torch's own kernels: MIOpen's NHWC BatchNorm crashed on one of these shapes)
+        z = F.batch_norm(yr, None, None, gr, br, True, 0.1, 1e-5)
+        z = F.relu(z) if act == 1 else (F.leaky_relu(z, 0.2) if act == 2 else z)
+        z.backward(gz.float().contiguous())
+    mean = y.float().mean((0, 2, 3))
+    invstd = (y.float().var((0, 2, 3), unbiased=False) + 1e-5).rsqrt()
+    scale, shift = gamma * invstd, beta - mean * gamma * invstd
+    gy, dgamma, dbeta = A.bn_bwd(gz, y, scale, shift, mean, invstd, act)
+    assert _rel(gy, yr.grad) <= tol, _rel(gy, yr.grad)
+    assert _rel(dgamma, gr.grad) <= 1e-3 and _rel(dbeta, br.grad) <= 1e-3
+    # a second sample group accumulating into the same parameter gradients
+    _, dg2, db2 = A.bn_bwd(gz, y, scale, shift, mean, invstd, act, params=(dgamma.clone(), dbeta.clone()))
+    torch.testing.assert_close(dg2, 2 * dgamma, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(db2, 2 * dbeta, rtol=1e-6, atol=1e-6)

@@ -12,6 +12,11 @@ SHAPES = [  # name, Cin, H, W, Cout, k, stride, pad, pad_mode, transposed, opad
     ("down3x3s2_128->256@512x1024", 128, 512, 1024, 256, 3, 2, 1, 0, False, 0),
     ("up3x3T_1024->512@64x128", 1024, 64, 128, 512, 3, 2, 1, 0, True, 1),
     ("D4x4s2_64->128@257x513", 64, 257, 513, 128, 4, 2, 2, 0, False, 0),
+    # training sizes (G0 at 256x512: residual blocks at 32x64)
+    ("up3x3T_1024->512@32x64", 1024, 32, 64, 512, 3, 2, 1, 0, True, 1),
+    ("up3x3T_512->256@64x128", 512, 64, 128, 256, 3, 2, 1, 0, True, 1),
+    ("up3x3T_256->128@128x256", 256, 128, 256, 128, 3, 2, 1, 0, True, 1),
+    ("down3x3s2_512->1024@64x128", 512, 64, 128, 1024, 3, 2, 1, 0, False, 0),
 ]
 
 
