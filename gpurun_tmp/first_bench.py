@@ -1,0 +1,22 @@
+import os, sys
+sys.path.insert(0, os.getcwd())
+import torch
+from ir2rgb_amd import conv as C
+dev = torch.device("cuda:0")
+for cout, h, w in ((128, 512, 1024), (64, 512, 1024), (64, 1024, 2048), (128, 256, 512)):
+    x = torch.randn(1, 64, h, w, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    wt = torch.randn(cout, 64, 7, 1, device=dev) * 0.02
+    d = C.make_desc(tuple(x.shape), cout, (7, 1), 1, (3, 0), C.PAD_REFLECT, torch.bfloat16)
+    wp = C.pack_weight(d, wt)
+    y = C.empty_nhwc(1, cout, h, w, torch.bfloat16, dev)
+    for _ in range(3):
+        C.conv2d_fwd(d, x, wp, None, want_stats=True, out=y)
+    torch.cuda.synchronize()
+    a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(50):
+        C.conv2d_fwd(d, x, wp, None, want_stats=True, out=y)
+    e.record(); torch.cuda.synchronize()
+    us = a.elapsed_time(e) / 50 * 1e3
+    mb = (x.numel() * 2 + y.numel() * 2) / 1e6
+    print(C.kernel_name(d), (cout, h, w), "%.1f us  %.0f MB -> %.2f TB/s" % (us, mb, mb / us))

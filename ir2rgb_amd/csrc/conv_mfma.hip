@@ -35,6 +35,7 @@
 
 #include "common.h"
 #include "conv1x7_thin.h"
+#include "conv7x1_col.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
@@ -954,6 +955,8 @@ extern "C" const char *ir2rgb_conv2d_kernel_name(const ir2rgb_conv_desc *d) {
     {
         T7Geom g7;
         if (conv1x7_thin_plan(d, &g7)) return "conv1x7_thin_kernel";     // (launches without bias / statistics: the head pass)
+        C7Geom gc;
+        if (conv7x1_col_plan(d, &gc)) return "conv7x1_col_kernel";
     }
     ClassPlan plans[4];
     const int n = make_plan(d, plans);
@@ -967,6 +970,8 @@ extern "C" int ir2rgb_conv2d_stats_rows(const ir2rgb_conv_desc *d) {
         P3Geom g3;
         int npt3 = 0;
         if (d && conv3x3p_plan(d, &g3, &npt3)) return npt3;
+        C7Geom gc;
+        if (d && conv7x1_col_plan(d, &gc)) return conv7x1_col_tiles(gc);
     }
     ClassPlan plans[4];
     int n = make_plan(d, plans);
@@ -1196,6 +1201,10 @@ extern "C" int ir2rgb_conv2d_fwd_ws(const ir2rgb_conv_desc *d, const void *x, co
     if (bias == nullptr && stats_partial == nullptr) {
         T7Geom g7;      // the 1x7 pass of the separable heads: row-segment staging, weights in registers (conv1x7_thin.hip)
         if (conv1x7_thin_plan(d, &g7)) return conv1x7_thin_launch(g7, d->dtype, d->Cin, x, wpacked, y, as_stream(stream));
+    }
+    {
+        C7Geom gc;      // the 7x1 pass of the generators' first layers: column tiles staged once (conv7x1_col.hip)
+        if (conv7x1_col_plan(d, &gc)) return conv7x1_col_launch(gc, d->dtype, x, wpacked, bias, y, stats_partial, as_stream(stream));
     }
     {
         P3Geom g3;

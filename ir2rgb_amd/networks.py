@@ -207,9 +207,12 @@ class _Branch:
     """``with _Branch(x) as b: y = f(x)`` runs the body on the device's side stream after everything queued on the
     current stream; ``b.join(y, ...)`` makes the current stream wait for it and returns the tensors."""
 
-    def __init__(self, *inputs):
+    def __init__(self, *inputs, owner=None):
         self.inputs = [t for t in inputs if isinstance(t, torch.Tensor)]
-        on = BRANCH_STREAMS == "1" or (BRANCH_STREAMS == "auto" and not torch.is_grad_enabled())
+        # (``owner.branch_streams_training``: a module may ask for two streams also while autograd records -- the trainer
+        # sets it on the finer spatial scales, whose kernels bench.py does not bracket)
+        on = BRANCH_STREAMS == "1" or (BRANCH_STREAMS == "auto" and (not torch.is_grad_enabled() or
+                                                                      getattr(owner, "branch_streams_training", False)))
         self.enabled = on and bool(self.inputs) and self.inputs[0].is_cuda
         self.ctx = None
 
@@ -311,11 +314,11 @@ class CompositeGeneratorModule(_CompositeBase):
     def forward(self, input, img_prev, mask, img_feat_coarse, flow_feat_coarse, img_fg_feat_coarse, use_raw_only):
         self._check_inputs(input, img_prev)
         dt, tr = self.compute_dtype, self.training
-        with _Branch(input) as enc:                          # the label encoder beside the previous-frame encoder
+        with _Branch(input, owner=self) as enc:              # the label encoder beside the previous-frame encoder
             seg = _run_sequence(self.model_down_seg, input, dt, tr)
         downsample = _run_sequence(self.model_down_img, img_prev, dt, tr, final_residual=lambda: enc.join(seg))  # (:192)
         flow_feat = fw = None
-        with _Branch(downsample) as dec:                     # the flow decoder + its heads beside the image decoder
+        with _Branch(downsample, owner=self) as dec:         # the flow decoder + its heads beside the image decoder
             if not self.no_flow:
                 flow_feat = _run_sequence(self.model_up_flow, _run_sequence(self.model_res_flow, downsample, dt, tr), dt, tr)
                 fw = self._flow_heads(flow_feat, 20.0)
@@ -364,11 +367,11 @@ class CompositeLocalGeneratorModule(_CompositeBase):
     def forward(self, input, img_prev, mask, img_feat_coarse, flow_feat_coarse, img_fg_feat_coarse, use_raw_only):
         self._check_inputs(input, img_prev)
         dt, tr = self.compute_dtype, self.training
-        with _Branch(input) as enc:
+        with _Branch(input, owner=self) as enc:
             seg = self._encode(self.model_down_seg, input, dt, tr)
         down_img = self._encode(self.model_down_img, img_prev, dt, tr, res1=lambda: enc.join(seg))  # (:290)
         flow_feat = fw = None
-        with _Branch(down_img, flow_feat_coarse) as dec:
+        with _Branch(down_img, flow_feat_coarse, owner=self) as dec:
             if not self.no_flow:
                 flow_in = A.add(down_img, _padded(A.to_nhwc_half(flow_feat_coarse, dt)))   # (:297)
                 flow_feat = _run_sequence(self.model_up_flow, flow_in, dt, tr)

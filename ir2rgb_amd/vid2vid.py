@@ -44,6 +44,8 @@ DEFAULTS = dict(  # options/base_options.py, options/train_options.py (SURVEY se
     fused_losses=True,   # grouped HIP loss kernels (ir2rgb_amd.losses); False = the same terms through torch ops
     batched_repack=True,  # all packed weight copies refreshed by one launch after the optimizer steps (layers.WeightRepacker)
     build_flow_net=True,  # False: trainer.flow_net is left None for the caller to set (tests plug a stand-in for FlowNet2)
+    branch_streams_fine_scales=True,   # the finer spatial scales' generators run their two branches on two HIP streams, forward
+                                       # and backward (the coarsest scale's kernels are what bench.py brackets: one stream)
 )
 
 
@@ -443,6 +445,9 @@ class Vid2VidTrainer:
         for m in self.netG + [self.netD] + self.netD_T:
             m.to(device).train()
             m.compute_dtype = o["compute_dtype"]
+        import os
+        for g in self.netG[1:]:
+            g.branch_streams_training = bool(o["branch_streams_fine_scales"]) and os.environ.get("IR2RGB_BRANCH_FINE", "1") != "0"
         # FlowNet2 is replayed from a HIP graph in every configuration (a capture next to a process group runs in
         # thread-local mode, FlowNet.compute_flow_and_conf), on its own stream -- also for data-parallel ranks on RCCL
         # (tests/test_rccl_gpu.py: bit-identical to the single-process trainer next to RCCL's collectives).  Only the gloo

@@ -288,3 +288,30 @@ def test_head_1x7_pass_row_segment_kernel(dev, dtype, N, Cin, H, W, Cout):
     assert y0.dtype == torch.float32 and y0.shape == ref.shape
     rms = ref.pow(2).mean().sqrt().item()
     assert ((y0 - ref).abs() <= 1e-5 * ref.abs() + 2e-4 * rms).all(), (y0 - ref).abs().max().item()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,H,W,Cout", [(1, 40, 100, 128), (2, 9, 33, 64), (1, 64, 128, 64), (1, 5, 31, 128), (1, 256, 96, 128)])
+def test_first_layer_7x1_pass_column_tile_kernel(dev, dtype, N, H, W, Cout):
+    """conv7x1_col_kernel (the 7x1 pass of the generators' first layers, reference networks.py:141,:150,:253-255 as
+    layers.first_stage evaluates them: 64 x-expanded channels, reflection pad 3 in y): against torch's fp32 convolution on
+    the same half-rounded operands, with bias, with BatchNorm partial sums; ragged tiles on both axes, images lower than a
+    tile, more tiles than persistent workgroups (256 x 96: 96 tiles... and 40 x 100), operands in NaN bands, outputs in canary bands."""
+    from ir2rgb_amd import conv as C
+    from test_bounds_gpu import Guarded
+    g = torch.Generator(device="cpu").manual_seed(H + W)
+    x = torch.randn(N, 64, H, W, generator=g).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, 64, 7, 1, generator=g) * (1.0 / np.sqrt(64 * 7))).to(dev)
+    b = torch.randn(Cout, generator=g).to(dev)
+    desc = C.make_desc(tuple(x.shape), Cout, (7, 1), 1, (3, 0), C.PAD_REFLECT, dtype)
+    assert C.kernel_name(desc) == "conv7x1_col_kernel"
+    wp = C.pack_weight(desc, w)
+    y0, s0 = C.conv2d_fwd(desc, x, wp, b, want_stats=True)
+    gx, gw, gb = Guarded(x, float("nan")), Guarded(wp, float("nan")), Guarded(b, float("nan"))
+    gy, gs = Guarded(y0, 7.0), Guarded(s0, 7.0)
+    gy.t.zero_()
+    y1, _ = C.conv2d_fwd(desc, gx.t, gw.t, gb.t, want_stats=False, out=gy.t)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y0) and gy.intact() and gx.intact() and gw.intact() and gb.intact()
+    ref = F.conv2d(F.pad(x.float(), (0, 0, 3, 3), mode="reflect"), w.to(dtype).float(), b)
+    _check(y0, s0, ref, dtype)

@@ -328,8 +328,12 @@ def test_training_windows_vs_reference_golden(dev, golden_dir, case, dtype):
                     l2, pr = ((a - b).norm() / b.norm()).item(), abs((a @ b / (b @ b)).item() - 1.0)
                     report[f"{tag}/{k}"] = (round(l2, 4), round(floor[f"{tag}/l2/{k}"], 4), round(pr, 4), round(floor[f"{tag}/proj/{k}"], 4))
                     assert l2 <= _floor_tol(floor[f"{tag}/l2/{k}"], 2.0, 0.03), (tag, k, "relative L2", l2, floor[f"{tag}/l2/{k}"])
-                    # (zero-mean noise of relative size e moves the projection by at most e: half the L2 floor as a third term)
-                    ptol = max(_floor_tol(floor[f"{tag}/proj/{k}"], 1.5, 0.03), 0.5 * floor[f"{tag}/l2/{k}"])
+                    # (zero-mean noise of relative size e moves the projection by at most e: half the L2 floor as a third term.
+                    # The floor is ONE sample of rounding noise -- the emulation's; an implementation that sums a BatchNorm
+                    # statistic in another order is another sample: round 3's column-tile first-layer kernel moved G1's
+                    # flow-head weight, the noisiest tensor (relative L2 0.4), from 0.08 to 0.113 at a floor of 0.063 with its
+                    # own output bit-checked against torch.  Hence twice the floor, as for the L2 distance.)
+                    ptol = max(_floor_tol(floor[f"{tag}/proj/{k}"], 2.0, 0.03), 0.5 * floor[f"{tag}/l2/{k}"])
                     assert pr <= ptol, (tag, k, "projection", pr, floor[f"{tag}/proj/{k}"])
             print(case, dtype, "window-0 gradients (l2, floor, |proj-1|, floor):", report)
     print(case, dtype, "worst per term", {k: round(v, 4) for k, v in worst.items()})
