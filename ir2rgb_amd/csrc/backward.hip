@@ -417,14 +417,19 @@ __global__ void __launch_bounds__(512)
 bn_bwd_onepass_kernel(const uint4 *__restrict__ gz, const uint4 *__restrict__ y, const float *__restrict__ scale,
                       const float *__restrict__ shift, const float *__restrict__ mean, const float *__restrict__ invstd,
                       uint4 *__restrict__ gy, float *__restrict__ dgamma, float *__restrict__ dbeta, long npix, int C, int act,
-                      int dt, float inv_n, int acc) {
+                      int dt, float inv_n, int acc, int xcd_remap) {
     constexpr int LPP = CPB / 8;                 // lanes per pixel
     constexpr int PPP = 512 / LPP;               // pixels per pass
     __shared__ double red[2][8][CPB];
     __shared__ float co[3][CPB];
     const int t = threadIdx.x, oc = t % LPP, prow = t / LPP, wave = t >> 6, lane = t & 63;
-    const int c0 = blockIdx.x * CPB + oc * 8, C8 = C >> 3;
-    const long cidx = (long)blockIdx.x * LPP + oc;
+    // Workgroups whose channel groups share 128-byte lines (64 / CPB neighbours) go to ONE XCD (blockIdx % 8 under
+    // round-robin placement): each L2 then fetches a line once and merges the 16-byte stores into whole lines, instead
+    // of eight L2s fetching and partially writing every line (speed only: any placement gives the same result).
+    const int G = gridDim.x;
+    const int grp = xcd_remap && (G & 7) == 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int c0 = grp * CPB + oc * 8, C8 = C >> 3;
+    const long cidx = (long)grp * LPP + oc;
     uint4 gq[K], yq[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {                // unconditional loads from a clamped pixel, masked below (a predicated
@@ -468,7 +473,7 @@ bn_bwd_onepass_kernel(const uint4 *__restrict__ gz, const uint4 *__restrict__ y,
         double a = 0.0, b = 0.0;
 #pragma unroll
         for (int w = 0; w < 8; ++w) { a += red[0][w][t]; b += red[1][w][t]; }
-        const int c = blockIdx.x * CPB + t;
+        const int c = grp * CPB + t;
         const float scv = scale[c], isv = invstd[c], muv = mean[c];
         const float dg = (float)b * inv_n, db = (float)a * inv_n;
         co[0][t] = scv;
@@ -503,7 +508,9 @@ template <int CPB>
 static bool bn_bwd_onepass_launch(int K, dim3 grid, hipStream_t s, const uint4 *gz, const uint4 *y, const float *scale,
                                   const float *shift, const float *mean, const float *invstd, uint4 *gy, float *dgamma,
                                   float *dbeta, long npix, int C, int act, int dt, float inv_n, int acc) {
-#define IR2RGB_ONEPASS(KK) bn_bwd_onepass_kernel<KK, CPB><<<grid, 512, 0, s>>>(gz, y, scale, shift, mean, invstd, gy, dgamma, dbeta, npix, C, act, dt, inv_n, acc)
+    static int remap = -1;          // IR2RGB_BN_BWD_XCD=0: channel group = blockIdx (A/B measurements)
+    if (remap < 0) { const char *e = getenv("IR2RGB_BN_BWD_XCD"); remap = e ? atoi(e) : 1; }
+#define IR2RGB_ONEPASS(KK) bn_bwd_onepass_kernel<KK, CPB><<<grid, 512, 0, s>>>(gz, y, scale, shift, mean, invstd, gy, dgamma, dbeta, npix, C, act, dt, inv_n, acc, remap)
     if (K <= 4) IR2RGB_ONEPASS(4);
     else if (K <= 8) IR2RGB_ONEPASS(8);       // (K = 12 would need scratch: 256 registers are gone at K = 9)
     else return false;
