@@ -178,6 +178,34 @@ def test_fold_reflect_and_xexpand_adjoints(dev):
         assert abs(lhs.item() - rhs.item()) <= 5e-3 * abs(lhs.item()) + 0.5, (kw, lhs.item(), rhs.item())
 
 
+@pytest.mark.parametrize("case", [
+    # Cin, W, KW, stride, pad, reflect
+    (9, 300, 7, 1, 3, 1),       # the generators' 7-wide first layer: three 128-column tiles, ragged last one, both mirrors
+    (16, 300, 4, 2, 2, 0),      # the discriminators' stride-2 first layer at the channel limit (16 x 4 = 64)
+    (6, 257, 4, 2, 1, 0),       # odd width: a one-column last tile
+    (6, 128, 3, 1, 1, 1),       # exactly one tile
+    (3, 131, 7, 1, 3, 1),       # the right mirrors start in the tile BEFORE the last (3 columns wide)
+    (5, 2, 3, 1, 1, 1),         # narrower than the kernel
+])
+def test_xexpand_bwd_row_tile_kernel_vs_autograd(dev, case):
+    """ir2rgb_xexpand_bwd (rows of the expanded gradient staged once per 128-column tile) against autograd through a
+    plain-torch restatement of the expansion (pad along x, unfold): fp32 sums of the same half values."""
+    from ir2rgb_amd import autograd as A
+    cin, w, kw, sx, px, reflect = case
+    g = torch.Generator().manual_seed(31)
+    n, h = 2, 5
+    wout = (w + 2 * px - kw) // sx + 1
+    d = torch.randn(n, 64, h, wout, generator=g).to(dev).to(torch.float16).contiguous(memory_format=torch.channels_last)
+    img = torch.zeros(n, cin, h, w, device=dev, requires_grad=True)
+    xp = F.pad(img, (px, px, 0, 0), mode="reflect" if reflect else "constant")
+    e = xp.unfold(3, kw, sx)                                  # [n, cin, h, wout, kw]
+    e = e.permute(0, 1, 4, 2, 3).reshape(n, cin * kw, h, wout)
+    (e * d[:, :cin * kw].float()).sum().backward()
+    got = A.xexpand_bwd(d, cin, w, kw, sx, px, reflect)
+    assert got.shape == img.grad.shape
+    torch.testing.assert_close(got, img.grad, atol=1e-4, rtol=1e-5)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", [
     # Cin, H, W, Cout, k, stride, pad, pad_mode, transposed, opad
