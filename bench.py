@@ -262,20 +262,25 @@ def main():
     elapsed = float(t.item())
 
     def traffic_of(key):
-        """HBM-side bytes per launch from the committed PMC passes (profiles/r02_dominant_conv_traffic.json); None
-        for a shape they do not cover.  (PMC counters cannot be collected inside this process.)"""
+        """(HBM-side bytes per launch, where they were measured) from the committed PMC passes
+        (profiles/r03_dominant_conv_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/conv_hot.py,
+        the file names the commit they were taken at); (None, None) for a shape they do not cover.  PMC counters cannot be
+        collected inside this process."""
         try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_dominant_conv_traffic.json")) as f:
-                return json.load(f)["shapes"].get(",".join(v if isinstance(v, str) else str(int(v)) for v in key))
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_dominant_conv_traffic.json")) as f:
+                doc = json.load(f)
+            v = doc["shapes"].get(",".join(v if isinstance(v, str) else str(int(v)) for v in key))
+            return v, (None if v is None else "%s @ commit %s (PMC passes outside this run)" % (doc["source"], doc["commit"]))
         except OSError:
-            return None
+            return None, None
 
     # ---- roofline of the dominant kernel: HIP events around each of its launches inside the timed region
     tot, n_launch, flops, kernel_name = prof[dominant]
     avg = tot / n_launch
     achieved = flops / avg / 1e12
+    traffic, traffic_source = traffic_of(dominant)
     roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic_of(dominant),
+                "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": kernel_name + " (MFMA implicit GEMM)",
                 "shape": dict(zip(("Cin", "Hin", "Win", "Cout", "kh", "kw", "stride", "reflect", "transposed"), dominant)),
                 "launches": n_launch, "avg_us": round(avg * 1e6, 1), "flops_per_launch": flops,

@@ -25,31 +25,36 @@ static __device__ __forceinline__ uint16_t f2h(float f, int dt) {
 // of two rows (coalesced 128 B each), row groups stride the partial rows, LDS combines them.
 // Sums in double: var = E[y^2] - E[y]^2.
 // ----------------------------------------------------------------------------------------
+// CL = 8 (8 channels x 128 row groups): four times the workgroups for layers with thousands of partial rows and few
+// channels (the 64-channel layers of a 1024x2048 frame write 16384 rows: two 32-channel workgroups walked them in
+// 64 dependent rounds, 48 us; eight workgroups of 128 row groups need 16).
+template <int CL>
 __global__ void __launch_bounds__(1024)
 bn_finalize_kernel(const float *__restrict__ partial, int rows, int C, double count, const float *__restrict__ gamma,
                    const float *__restrict__ beta, const float *__restrict__ conv_bias, float *__restrict__ running_mean,
                    float *__restrict__ running_var, float momentum, float eps, float *__restrict__ scale,
                    float *__restrict__ shift, float *__restrict__ mean_out, float *__restrict__ invstd_out,
                    int stat_updates) {
-    __shared__ double red[2][32][33];
-    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    constexpr int RG = 1024 / CL;
+    __shared__ double red[2][RG][CL + 1];
+    const int cl = threadIdx.x % CL, rg = threadIdx.x / CL;
+    const int c = blockIdx.x * CL + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < C)
-        for (int r = rg; r < rows; r += 32 * 8) {
+        for (int r = rg; r < rows; r += RG * 8) {
             // eight row pairs in flight per thread (the plain loop waits for every pair: ~0.2 us x rows/32, 23 us
             // for the 4096 partial rows of a full-resolution layer).  The loads are unconditional on a clamped row
             // and masked afterwards: a predicated load compiles to a branch with its own wait, i.e. serial again.
             float a[8], b[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int rr = min(r + 32 * u, rows - 1);
+                const int rr = min(r + RG * u, rows - 1);
                 a[u] = partial[((long)rr * 2 + 0) * C + c];
                 b[u] = partial[((long)rr * 2 + 1) * C + c];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const bool ok = r + 32 * u < rows;
+                const bool ok = r + RG * u < rows;
                 s1 += ok ? (double)a[u] : 0.0;      // summed in row order, as the plain loop
                 s2 += ok ? (double)b[u] : 0.0;
             }
@@ -62,7 +67,7 @@ bn_finalize_kernel(const float *__restrict__ partial, int rows, int C, double co
     // unrolled in full the 64 doubles are all loaded first: 128 VGPRs = the cap of a 1024-thread block, and the
     // compiler spilled 7 of them (a kernel with scratch pays for it at every dispatch)
 #pragma unroll 8
-    for (int r = 0; r < 32; ++r) { s1 += red[0][r][cl]; s2 += red[1][r][cl]; }
+    for (int r = 0; r < RG; ++r) { s1 += red[0][r][cl]; s2 += red[1][r][cl]; }
     double mean = s1 / count;
     double var = s2 / count - mean * mean;
     var = var > 0.0 ? var : 0.0;
@@ -409,9 +414,16 @@ extern "C" int ir2rgb_bn_finalize_ex(const float *stats_partial, int rows, int C
         return ir2rgb_launch_status();
     }
     if (rows < 1 || count < 1 || !stats_partial || stat_updates < 1) return IR2RGB_EINVAL;
-    bn_finalize_kernel<<<cdiv(C, 32), 1024, 0, as_stream(stream)>>>(stats_partial, rows, C, (double)count, gamma, beta,
-                                                                    conv_bias, running_mean, running_var, momentum, eps,
-                                                                    scale, shift, mean_out, invstd_out, stat_updates);
+    static int narrow = -1;     // IR2RGB_BN_FINALIZE_NARROW=0: 32-channel workgroups for every layer (A/B measurements)
+    if (narrow < 0) { const char *e = getenv("IR2RGB_BN_FINALIZE_NARROW"); narrow = e ? atoi(e) : 1; }
+    if (narrow && rows >= 2048 && C <= 256)
+        bn_finalize_kernel<8><<<cdiv(C, 8), 1024, 0, as_stream(stream)>>>(stats_partial, rows, C, (double)count, gamma, beta,
+                                                                         conv_bias, running_mean, running_var, momentum, eps,
+                                                                         scale, shift, mean_out, invstd_out, stat_updates);
+    else
+        bn_finalize_kernel<32><<<cdiv(C, 32), 1024, 0, as_stream(stream)>>>(stats_partial, rows, C, (double)count, gamma, beta,
+                                                                           conv_bias, running_mean, running_var, momentum, eps,
+                                                                           scale, shift, mean_out, invstd_out, stat_updates);
     return ir2rgb_launch_status();
 }
 

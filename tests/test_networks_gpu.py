@@ -329,6 +329,38 @@ def test_fused_bn_finalize_apply_is_bit_identical(dev, dtype, shape):
     assert torch.isfinite(outs[0][0].float()).all()
 
 
+@pytest.mark.parametrize("rows,ch", [(16384, 64), (4096, 128), (2048, 24), (2047, 64), (5000, 512), (1, 64)])
+def test_bn_finalize_many_partial_rows_vs_float64(dev, rows, ch):
+    """ir2rgb_bn_finalize_ex over thousands of partial rows (the statistics of a 1024x2048 layer: 16384 rows; narrow 8-channel
+    workgroups from 2048 rows on for <= 256 channels, 32-channel ones otherwise) against the same sums in float64:
+    scale, shift, mean, invstd and the running statistics of nn.BatchNorm2d."""
+    from ir2rgb_amd import layers as L
+    gen = torch.Generator().manual_seed(rows + ch)
+    count = rows * 128
+    m = torch.randn(ch, generator=gen).double() * 0.5
+    sd = torch.rand(ch, generator=gen).double() + 0.3
+    # per-tile sums of 128 values with per-channel mean m and deviation sd (rounded to fp32 as the conv epilogue writes them)
+    s1 = (128 * m + (128 ** 0.5) * sd * torch.randn(rows, ch, generator=gen).double()).float()
+    s2 = (128 * (sd * sd + m * m) * (1 + 0.05 * torch.randn(rows, ch, generator=gen).double())).float()
+    stats = torch.stack([s1, s2], 1).contiguous().to(dev)          # [rows][2][C]
+    bn = torch.nn.BatchNorm2d(ch).to(dev)
+    with torch.no_grad():
+        bn.weight.normal_(1.0, 0.2)
+        bn.bias.normal_(0.0, 0.2)
+    bias = torch.randn(ch, generator=gen).to(dev)
+    scale, shift, mean, invstd = L.bn_finalize(stats, count, bn, True, bias)
+    mean64 = s1.double().sum(0) / count
+    var64 = (s2.double().sum(0) / count - mean64 * mean64).clamp_min(0)
+    inv64 = 1.0 / torch.sqrt(var64 + bn.eps)
+    g64, b64 = bn.weight.detach().double().cpu(), bn.bias.detach().double().cpu()
+    torch.testing.assert_close(mean.cpu().double(), mean64, atol=1e-6, rtol=1e-6)
+    torch.testing.assert_close(invstd.cpu().double(), inv64, atol=0, rtol=2e-6)
+    torch.testing.assert_close(scale.cpu().double(), g64 * inv64, atol=1e-7, rtol=2e-6)
+    torch.testing.assert_close(shift.cpu().double(), b64 - mean64 * g64 * inv64, atol=2e-6, rtol=2e-6)
+    torch.testing.assert_close(bn.running_mean.cpu().double(), 0.1 * (mean64 + bias.cpu().double()), atol=1e-6, rtol=1e-5)
+    torch.testing.assert_close(bn.running_var.cpu().double(), 0.9 + 0.1 * var64 * count / (count - 1), atol=1e-6, rtol=1e-5)
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(1, 6, 70, 90), (2, 13, 64, 96)])
 def test_discriminator_sample_groups_equal_separate_forwards(dev, dtype, shape):

@@ -17,7 +17,18 @@ SHAPES = [  # name, Cin, H, W, Cout, k, stride, pad, pad_mode, transposed, opad
     ("up3x3T_512->256@64x128", 512, 64, 128, 256, 3, 2, 1, 0, True, 1),
     ("up3x3T_256->128@128x256", 256, 128, 256, 128, 3, 2, 1, 0, True, 1),
     ("down3x3s2_512->1024@64x128", 512, 64, 128, 1024, 3, 2, 1, 0, False, 0),
+    # sub-pixel-class launches of a training window: G1's up-sampler and the discriminators' data gradients
+    ("up3x3T_128->64@256x512", 128, 256, 512, 64, 3, 2, 1, 0, True, 1),
+    ("D4x4s2T_128->64@129x257", 128, 129, 257, 64, 4, 2, 2, 0, True, 1),
+    ("D4x4s2T_256->128@65x129", 256, 65, 129, 128, 4, 2, 2, 0, True, 1),
+    ("D4x4s2T_128->64@65x129", 128, 65, 129, 64, 4, 2, 2, 0, True, 1),
+    ("D4x4s2T_256->128@33x65", 256, 33, 65, 128, 4, 2, 2, 0, True, 1),
+    ("D4x4s1_512->256@66x130(dgrad)", 512, 66, 130, 256, 4, 1, 1, 0, False, 0),
+    ("D4x4s1_512->256@34x66(dgrad)", 512, 34, 66, 256, 4, 1, 1, 0, False, 0),
+    ("D4x4s1_64->512@67x131(dgrad)", 64, 67, 131, 512, 4, 1, 1, 0, False, 0),
 ]
+if os.environ.get("ONLY"):
+    SHAPES = [s for s in SHAPES if os.environ["ONLY"] in s[0]]
 
 
 def main():
