@@ -53,7 +53,10 @@ int ir2rgb_correlation_out_shape(int C, int H, int W, int pad_size, int kernel_s
  * (rInput1/rInput2) are needed.
  * Replaces correlation_cuda.forward:
  *   correlation_package/correlation_cuda.cc:10-87 and
- *   correlation_package/correlation_cuda_kernel.cu:46-147, :336-427. */
+ *   correlation_package/correlation_cuda_kernel.cu:46-147, :336-427.
+ * Status: operator API (the reference's fp32 NCHW boundary, BASELINE config 3: 65 us at [1,256,64,128] = 0.48 TB/s, fp32 VALU
+ * bound).  The FlowNet2 pipeline of this package does not call it: FlowNetC's cost volume is taken from the half NHWC conv3
+ * outputs by ir2rgb_correlation_nhwc_half below (18.6 us); both are parity-tested against the same oracle. */
 int ir2rgb_correlation_fwd(const float *in1, const float *in2, float *out, int N, int C, int H, int W,
                            int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
                            void *stream);
