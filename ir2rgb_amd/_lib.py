@@ -121,8 +121,21 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        _lib = handle
+        # fastcall wrappers (ir2rgb_amd/fastbind.py: ~0.5 us per call instead of ctypes' 6-9 us) for every entry point they
+        # cover; the ctypes functions for the rest and when the extension is not built
+        from . import fastbind
+        fast = fastbind.load()
+        ns = _Entry()
+        ns.ctypes_handle = handle
+        ns.fast_module = fast
+        for name in PROTOTYPES:
+            setattr(ns, name, getattr(fast, name, None) or getattr(handle, name))
+        _lib = ns
     return _lib
+
+
+class _Entry:
+    """Namespace of the library's entry points (fastcall wrapper where one exists, else the ctypes function)."""
 
 
 _ERRNAMES = {-1: "IR2RGB_EINVAL (bad size/parameter)", -2: "IR2RGB_ENOSUP (not supported)",
@@ -148,7 +161,7 @@ def current_stream(tensor):
         import torch
         _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (
             lambda idx: torch.cuda.current_stream(idx).cuda_stream)
-    return c_void_p(_RAW_STREAM(tensor.device.index))
+    return _RAW_STREAM(tensor.device.index)     # (an int: see ir2rgb_amd/fastbind.py)
 
 
 class _NullCtx:

@@ -26,10 +26,13 @@ from . import layers as L
 from . import streamcheck as SC
 
 _DT = {torch.bfloat16: 1, torch.float16: 2}
+_ADJ_DESCS = {}      # adjoint descriptors of strided convolutions (conv_dgrad), one object per geometry
 
 
 def _p(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+    # (a plain int: accepted by the fastcall bindings and by ctypes' c_void_p parameters alike; a c_void_p object per
+    # argument cost 0.75 us, ten of them per launch)
+    return t.data_ptr() if t is not None else 0
 
 
 def _as_half_nhwc(g, dtype):
@@ -51,17 +54,20 @@ def bn_bwd(gz, y, scale, shift, mean, invstd, act, out=None, params=None):
     if nblk < 0:
         _lib.check(nblk, "bn_bwd_blocks")
     dev = y.device
-    partial = torch.empty((nblk * 2 + 3) * ch, dtype=torch.float32, device=dev)
     if params is not None:
         dgamma, dbeta = params
         act |= 32
+        buf = torch.empty((nblk * 2 + 3) * ch, dtype=torch.float32, device=dev)
+        ppartial = buf.data_ptr()
     else:
-        dgamma = torch.empty(ch, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(ch, dtype=torch.float32, device=dev)
+        # one allocation: [dgamma | dbeta | the kernel's partial rows] (the rows only ever exist as an address)
+        buf = torch.empty((nblk * 2 + 5) * ch, dtype=torch.float32, device=dev)
+        dgamma, dbeta = buf[:ch], buf[ch:2 * ch]
+        ppartial = buf.data_ptr() + 8 * ch
     gy = out if out is not None else torch.empty_like(y, memory_format=torch.channels_last)
     with _lib.on_device(y):
         rc = lib.ir2rgb_bn_bwd(_p(gz), _p(y), _p(scale), _p(shift), _p(mean), _p(invstd), _p(gy), _p(dgamma), _p(dbeta),
-                               _p(partial), npix, ch, act, _DT[y.dtype], _lib.current_stream(y))
+                               ppartial, npix, ch, act, _DT[y.dtype], _lib.current_stream(y))
     _lib.check(rc, "bn_bwd")
     return gy, dgamma, dbeta
 
@@ -225,8 +231,10 @@ def conv_dgrad(gy, conv, spec, x_shape, weight_fn=None, tag="dgrad", out=None):
     if spec["pad_mode"] != C.PAD_ZERO:
         raise NotImplementedError("data gradient of a strided reflect-padded convolution")
     hfull, wfull = (gy.shape[2] - 1) * sh - 2 * ph + kh, (gy.shape[3] - 1) * sw - 2 * pw + kw
-    desc = C.ConvDesc(n, gy.shape[2], gy.shape[3], gy.shape[1], hin, win, cin, kh, kw, sh, sw, ph, pw, C.PAD_ZERO, 1,
-                      _DT[dt], 0, 0, 0, 0, 0, 0)
+    key = (n, gy.shape[2], gy.shape[3], gy.shape[1], hin, win, cin, kh, kw, sh, sw, ph, pw, C.PAD_ZERO, 1, _DT[dt], 0, 0, 0, 0, 0, 0)
+    desc = _ADJ_DESCS.get(key)
+    if desc is None:
+        desc = _ADJ_DESCS[key] = C.sealed(C.ConvDesc(*key))
     assert 0 <= hin - hfull < sh and 0 <= win - wfull < sw, "adjoint geometry mismatch"
     wp = L.packed_weight(conv, desc, weight_fn, tag=tag)
     dx, _ = C.conv2d_fwd(desc, gy, wp, out=out)

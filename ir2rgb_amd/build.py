@@ -69,6 +69,8 @@ def build(force=False, verbose=False, jobs=None):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr)
+    from . import fastbind        # the CPython fastcall bindings of the same entry points (gcc, host code only)
+    fastbind.build(force=force)
     return LIB
 
 

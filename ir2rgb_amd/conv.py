@@ -20,7 +20,9 @@ ACT_NONE, ACT_LEAKY02 = 0, 1
 
 
 def _p(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+    # (a plain int: accepted by the fastcall bindings and by ctypes' c_void_p parameters alike; a c_void_p object per
+    # argument cost 0.75 us, ten of them per launch)
+    return t.data_ptr() if t is not None else 0
 
 
 def out_size(h, k, stride, pad, transposed=False, output_padding=0):
@@ -36,12 +38,37 @@ def _pair(v):
 def make_desc(x_shape, cout, k, stride, pad, pad_mode, dtype, transposed=False, output_padding=0, act=ACT_NONE,
               out_f32=False, ldx=0, ci_off=0, ldy=0, co_off=0, stats_per_sample=False):
     """x_shape = (N, Cin, H, W) logical; k / stride / pad = int or (h, w) pair."""
+    # Descriptors are immutable by convention and a layer asks for the same one every window: one object per distinct
+    # argument tuple, which also carries what is derived from it once (``_addr`` for the fastcall bindings, workspace
+    # sizes, statistics rows, kernel name) -- building the struct and asking the library again cost ~5 us per launch.
+    key = (x_shape, cout, k, stride, pad, pad_mode, dtype, transposed, output_padding, act, out_f32, ldx, ci_off, ldy, co_off,
+           stats_per_sample)
+    try:
+        hit = _DESCS.get(key)
+    except TypeError:           # (an unhashable shape, e.g. a list)
+        key, hit = None, None
+    if hit is not None:
+        return hit
     n, cin, h, w = x_shape
     (kh, kw), (sh, sw), (ph, pw) = _pair(k), _pair(stride), _pair(pad)
     ho = out_size(h, kh, sh, ph, transposed, output_padding)
     wo = out_size(w, kw, sw, pw, transposed, output_padding)
-    return ConvDesc(n, h, w, cin, ho, wo, cout, kh, kw, sh, sw, ph, pw, pad_mode, int(transposed), _TORCH2DT[dtype],
-                    act, int(out_f32), ldx, ci_off, ldy, co_off, int(stats_per_sample))
+    d = sealed(ConvDesc(n, h, w, cin, ho, wo, cout, kh, kw, sh, sw, ph, pw, pad_mode, int(transposed), _TORCH2DT[dtype],
+                        act, int(out_f32), ldx, ci_off, ldy, co_off, int(stats_per_sample)))
+    if key is not None:
+        if len(_DESCS) > 4096:
+            _DESCS.clear()
+        _DESCS[key] = d
+    return d
+
+
+_DESCS = {}
+
+
+def sealed(desc):
+    """A finished descriptor: ``_addr`` = its address (what the fastcall bindings of libir2rgb_hip.so take)."""
+    desc._addr = ctypes.addressof(desc)
+    return desc
 
 
 _KERNEL_NAMES = {}
@@ -49,10 +76,13 @@ _KERNEL_NAMES = {}
 
 def kernel_name(desc):
     """Device kernel ir2rgb_conv2d_fwd would launch for ``desc`` ('' if it cannot run it); cached per descriptor."""
-    key = bytes(desc)
-    name = _KERNEL_NAMES.get(key)
+    name = getattr(desc, "_kname", None)
     if name is None:
-        name = _KERNEL_NAMES[key] = _lib.lib().ir2rgb_conv2d_kernel_name(ctypes.byref(desc)).decode()
+        key = bytes(desc)
+        name = _KERNEL_NAMES.get(key)
+        if name is None:
+            name = _KERNEL_NAMES[key] = _lib.lib().ir2rgb_conv2d_kernel_name(ctypes.byref(desc)).decode()
+        desc._kname = name
     return name
 
 
@@ -84,7 +114,7 @@ class PackBatch:
             _lib.check(int(nbytes), "conv2d_pack_batch_table_bytes")
         host = torch.zeros(int(nbytes), dtype=torch.uint8)
         nblocks = ctypes.c_int(0)
-        n = lib.ir2rgb_conv2d_pack_batch_build(arr, len(jobs), ctypes.c_void_p(host.data_ptr()), int(nbytes),
+        n = lib.ir2rgb_conv2d_pack_batch_build(arr, len(jobs), host.data_ptr(), int(nbytes),
                                                ctypes.byref(nblocks))
         if n < 0:
             _lib.check(int(n), "conv2d_pack_batch_build")
@@ -103,22 +133,25 @@ def pack_weight(desc, weight, adjoint=False):
     ``desc`` is the data-gradient convolution of a stride-1 Conv2d and ``weight`` its forward weight."""
     _lib.require_device(weight, dtype=torch.float32)
     lib = _lib.lib()
-    n = lib.ir2rgb_conv2d_packed_weight_elems(ctypes.byref(desc))
+    n = lib.ir2rgb_conv2d_packed_weight_elems(desc)
     if n < 0:
         _lib.check(int(n), "conv2d_packed_weight_elems")
     dt = torch.bfloat16 if desc.dtype == BF16 else torch.float16
     packed = torch.empty(n, dtype=dt, device=weight.device)
     with _lib.on_device(weight):
         fn = lib.ir2rgb_conv2d_pack_weight_adjoint if adjoint else lib.ir2rgb_conv2d_pack_weight
-        rc = fn(ctypes.byref(desc), _p(weight), _p(packed), _lib.current_stream(weight))
+        rc = fn(desc, _p(weight), _p(packed), _lib.current_stream(weight))
     _lib.check(rc, "conv2d_pack_weight")
     return packed
 
 
 def stats_rows(desc):
-    r = _lib.lib().ir2rgb_conv2d_stats_rows(ctypes.byref(desc))
-    if r < 0:
-        _lib.check(r, "conv2d_stats_rows")
+    r = getattr(desc, "_stats_rows", None)
+    if r is None:
+        r = _lib.lib().ir2rgb_conv2d_stats_rows(desc)
+        if r < 0:
+            _lib.check(r, "conv2d_stats_rows")
+        desc._stats_rows = r
     return r
 
 
@@ -178,7 +211,7 @@ _SPLIT_WS = {}
 def _fwd_workspace(desc, x):
     n = getattr(desc, "_ws_bytes", None)         # (descriptors are built once per layer and shape and never edited)
     if n is None:
-        n = desc._ws_bytes = int(_lib.lib().ir2rgb_conv2d_fwd_workspace_bytes(ctypes.byref(desc)))
+        n = desc._ws_bytes = int(_lib.lib().ir2rgb_conv2d_fwd_workspace_bytes(desc))
         if n < 0:
             _lib.check(n, "conv2d_fwd_workspace_bytes")
     if n == 0:
@@ -212,7 +245,7 @@ def conv2d_fwd(desc, x, wpacked, bias=None, want_stats=False, out=None):
     with _lib.on_device(x):
         ws, ws_bytes = _fwd_workspace(desc, x)
         tok = _prof_begin(desc)
-        rc = _lib.lib().ir2rgb_conv2d_fwd_ws(ctypes.byref(desc), _p(x), _p(wpacked), _p(bias), _p(y), _p(stats), _p(ws), ws_bytes,
+        rc = _lib.lib().ir2rgb_conv2d_fwd_ws(desc, _p(x), _p(wpacked), _p(bias), _p(y), _p(stats), _p(ws), ws_bytes,
                                              _lib.current_stream(x))
     _lib.check(rc, "conv2d_fwd")
     if tok is not None:
@@ -232,9 +265,12 @@ def conv2d_wgrad(desc, x, gy, out=None, accumulate=False):
     lib = _lib.lib()
     if accumulate and out is None:
         raise ValueError("conv2d_wgrad: accumulate needs the tensor to add to (out)")
-    n = (lib.ir2rgb_conv2d_wgrad_acc_workspace_elems if accumulate else lib.ir2rgb_conv2d_wgrad_workspace_elems)(ctypes.byref(desc))
-    if n < 0:
-        _lib.check(int(n), "conv2d_wgrad_workspace_elems")
+    n = getattr(desc, "_wgrad_ws_acc" if accumulate else "_wgrad_ws", None)
+    if n is None:
+        n = (lib.ir2rgb_conv2d_wgrad_acc_workspace_elems if accumulate else lib.ir2rgb_conv2d_wgrad_workspace_elems)(desc)
+        if n < 0:
+            _lib.check(int(n), "conv2d_wgrad_workspace_elems")
+        setattr(desc, "_wgrad_ws_acc" if accumulate else "_wgrad_ws", n)
     ws = torch.empty(n, dtype=torch.float32, device=x.device)
     shape = (desc.Cin, desc.Cout, desc.kh, desc.kw) if desc.transposed else (desc.Cout, desc.Cin, desc.kh, desc.kw)
     if out is not None:
@@ -246,7 +282,7 @@ def conv2d_wgrad(desc, x, gy, out=None, accumulate=False):
     with _lib.on_device(x):
         fn = lib.ir2rgb_conv2d_wgrad_acc if accumulate else lib.ir2rgb_conv2d_wgrad
         tok = _prof_begin(desc, "wgrad") if PROFILE is not None else None
-        rc = fn(ctypes.byref(desc), _p(x), _p(gy), _p(dw), _p(ws), _lib.current_stream(x))
+        rc = fn(desc, _p(x), _p(gy), _p(dw), _p(ws), _lib.current_stream(x))
         if tok is not None:
             _prof_end(tok, desc, "conv_wgrad")
     _lib.check(rc, "conv2d_wgrad")
@@ -264,7 +300,7 @@ def conv2d_fwd_view(desc, xbuf, wpacked, bias, ybuf, stats=None):
         raise ValueError("conv2d_fwd_view: GPU tensors only (no CPU fallback)")
     tok = _prof_begin(desc)
     with _lib.on_device(xbuf):
-        rc = _lib.lib().ir2rgb_conv2d_fwd(ctypes.byref(desc), _p(xbuf), _p(wpacked), _p(bias), _p(ybuf), _p(stats),
+        rc = _lib.lib().ir2rgb_conv2d_fwd(desc, _p(xbuf), _p(wpacked), _p(bias), _p(ybuf), _p(stats),
                                           _lib.current_stream(xbuf))
     _lib.check(rc, "conv2d_fwd")
     if tok is not None:

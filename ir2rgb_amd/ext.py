@@ -17,7 +17,7 @@ _f32 = torch.float32
 
 
 def _p(t):
-    return ctypes.c_void_p(t.data_ptr())
+    return t.data_ptr()
 
 
 class correlation_cuda:
@@ -140,7 +140,7 @@ def warp_diff_norm(img1, img2, flow, want_warped=True, want_diff=True, want_norm
     warped = torch.empty_like(img2) if want_warped else None
     diff = torch.empty_like(img2) if want_diff else None
     norm = img2.new_empty(N, 1, H, W) if want_norm else None
-    null = ctypes.c_void_p(0)
+    null = 0
     with _lib.on_device(img1):
         rc = _lib.lib().ir2rgb_warp_diff_norm_fwd(_p(img1), _p(img2), _p(flow), _p(warped) if want_warped else null,
                                                   _p(diff) if want_diff else null, _p(norm) if want_norm else null,

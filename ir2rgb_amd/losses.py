@@ -96,8 +96,8 @@ class _FusedLossFn(Function):
         partial = torch.empty(lib.ir2rgb_loss_partial_elems(), dtype=torch.float32, device=dev)
         arr = _build_items(terms, tensors, None)
         with _lib.on_device(tensors[0]):
-            rc = lib.ir2rgb_loss_multi_fwd(arr, len(terms), dt, ctypes.c_void_p(partial.data_ptr()),
-                                           ctypes.c_void_p(out.data_ptr()), _lib.current_stream(tensors[0]))
+            rc = lib.ir2rgb_loss_multi_fwd(arr, len(terms), dt, partial.data_ptr(),
+                                           out.data_ptr(), _lib.current_stream(tensors[0]))
         _lib.check(rc, "loss_multi_fwd")
         ctx.terms, ctx.dt = terms, dt
         ctx.save_for_backward(*tensors)
@@ -124,7 +124,7 @@ class _FusedLossFn(Function):
             gout = gout.contiguous().float()
             arr = _build_items(terms, tensors, grads)
             with _lib.on_device(gout):
-                rc = _lib.lib().ir2rgb_loss_multi_bwd(arr, len(terms), ctx.dt, ctypes.c_void_p(gout.data_ptr()),
+                rc = _lib.lib().ir2rgb_loss_multi_bwd(arr, len(terms), ctx.dt, gout.data_ptr(),
                                                       _lib.current_stream(gout))
             _lib.check(rc, "loss_multi_bwd")
         res = [None] * len(tensors)

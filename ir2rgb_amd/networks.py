@@ -207,22 +207,30 @@ class _Branch:
     """``with _Branch(x) as b: y = f(x)`` runs the body on the device's side stream after everything queued on the
     current stream; ``b.join(y, ...)`` makes the current stream wait for it and returns the tensors."""
 
-    def __init__(self, *inputs, owner=None):
+    def __init__(self, *inputs, owner=None, slot=0, force=None):
         self.inputs = [t for t in inputs if isinstance(t, torch.Tensor)]
         # (``owner.branch_streams_training``: a module may ask for two streams also while autograd records -- the trainer
         # sets it on the finer spatial scales, whose kernels bench.py does not bracket)
-        on = BRANCH_STREAMS == "1" or (BRANCH_STREAMS == "auto" and (not torch.is_grad_enabled() or
-                                                                      getattr(owner, "branch_streams_training", False)))
-        self.enabled = on and bool(self.inputs) and self.inputs[0].is_cuda
+        # ``slot``: which of the device's side streams (0: the generators' second branch; the discriminators use their own,
+        # see MultiScaleDiscriminator.forward and Vid2VidTrainer.train_window).  ``force``: the caller decides (True / False)
+        # instead of IR2RGB_BRANCH_STREAMS.
+        if force is None:
+            on = BRANCH_STREAMS == "1" or (BRANCH_STREAMS == "auto" and (not torch.is_grad_enabled() or
+                                                                          getattr(owner, "branch_streams_training", False)))
+        else:
+            on = bool(force) and BRANCH_STREAMS != "0"
+        self.enabled = on and bool(self.inputs) and self.inputs[0].is_cuda and not torch.cuda.is_current_stream_capturing()
+        self.slot = slot
         self.ctx = None
 
     def __enter__(self):
         if self.enabled:
             dev = self.inputs[0].device
             self.main = torch.cuda.current_stream(dev)
-            self.side = _SIDE_STREAMS.get(dev.index)
+            key = dev.index if self.slot == 0 else (dev.index, self.slot)
+            self.side = _SIDE_STREAMS.get(key)
             if self.side is None:
-                self.side = _SIDE_STREAMS[dev.index] = torch.cuda.Stream(dev)
+                self.side = _SIDE_STREAMS[key] = torch.cuda.Stream(dev)
             self.side.wait_stream(self.main)
             for t in self.inputs:
                 t.record_stream(self.side)
@@ -508,6 +516,29 @@ class MultiScaleDiscriminator(nn.Module):
             raise ValueError("MultiScaleDiscriminator: the batch is not a multiple of sample_groups")
         result = []
         x = input.float().contiguous()
+        if getattr(self, "scale_streams", False) and self.num_D > 1:
+            # The PatchGANs of the pyramid are independent networks of small, latency-shaped layers (a 512-channel layer at
+            # 34 x 66 gives a convolution 36 workgroups for 256 CUs): the coarser scales run on their own HIP streams beside
+            # the finest one (set by the trainer, ``scale_streams``).  Under autograd every node's backward runs on the
+            # stream of its forward, so the backward passes overlap the same way.  Same kernels, same operands.
+            xs = [x]
+            for i in range(1, self.num_D):
+                xs.append(A.avg_pool3s2(xs[-1]))
+            pending = []
+            for i in range(1, self.num_D):
+                br = _Branch(xs[i], slot=8 + i, force=True)
+                with br:
+                    outs = _run_patchgan(self._groups(self.num_D - 1 - i), xs[i], self.compute_dtype, self.training,
+                                         sample_groups, group_order)
+                pending.append((br, outs))
+            outs0 = _run_patchgan(self._groups(self.num_D - 1), xs[0], self.compute_dtype, self.training, sample_groups,
+                                  group_order)
+            result.append(outs0 if self.getIntermFeat else [outs0[-1]])
+            for br, outs in pending:
+                br.join(*outs)
+                result.append(outs if self.getIntermFeat else [outs[-1]])
+            L.flush_bn_counters()
+            return result
         for i in range(self.num_D):
             outs = _run_patchgan(self._groups(self.num_D - 1 - i), x, self.compute_dtype, self.training, sample_groups,
                                  group_order)

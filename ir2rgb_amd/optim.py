@@ -134,7 +134,7 @@ class FusedAdam:
         self._copied[k].record()
         self.step_count += 1
         with _lib.on_device(self.exp_avg):
-            rc = _lib.lib().ir2rgb_adam_step(ctypes.c_void_p(self._rows_dev.data_ptr()), ctypes.c_void_p(self._blocks.data_ptr()),
+            rc = _lib.lib().ir2rgb_adam_step(self._rows_dev.data_ptr(), self._blocks.data_ptr(),
                                              self._blocks.shape[0], self.lr, self.betas[0], self.betas[1], self.eps,
                                              self.step_count, _lib.current_stream(self.exp_avg))
         _lib.check(rc, "adam_step")

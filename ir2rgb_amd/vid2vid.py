@@ -45,6 +45,7 @@ DEFAULTS = dict(  # options/base_options.py, options/train_options.py (SURVEY se
     batched_repack=True,  # all packed weight copies refreshed by one launch after the optimizer steps (layers.WeightRepacker)
     build_flow_net=True,  # False: trainer.flow_net is left None for the caller to set (tests plug a stand-in for FlowNet2)
     branch_streams_fine_scales=True,   # the finer spatial scales' generators run their two branches on two HIP streams, forward
+    discriminator_streams=True,        # the image discriminator's scales and the temporal discriminators each on their own HIP stream (forward and, through autograd, backward): independent networks of small layers that fill a fraction of the chip one at a time
                                        # and backward (the coarsest scale's kernels are what bench.py brackets: one stream)
 )
 
@@ -420,6 +421,12 @@ class FlatGrads:
             self.scale_after = None
 
 
+class _LossDict(dict):
+    """A dict of named loss terms that may also carry them as the vectors the fused loss kernels wrote
+    (``vecs`` = (image-term vector | None, discriminator-term vector, generator-term vector), see get_losses)."""
+    vecs = None
+
+
 class Vid2VidTrainer:
     """One rank's models, optimizers and per-sequence state; ``train_window`` is the loop body."""
 
@@ -448,6 +455,8 @@ class Vid2VidTrainer:
         import os
         for g in self.netG[1:]:
             g.branch_streams_training = bool(o["branch_streams_fine_scales"]) and os.environ.get("IR2RGB_BRANCH_FINE", "1") != "0"
+        self.d_streams = bool(o["discriminator_streams"]) and os.environ.get("IR2RGB_D_STREAMS", "1") != "0" and device.type == "cuda"
+        self.netD.scale_streams = self.d_streams
         # FlowNet2 is replayed from a HIP graph in every configuration (a capture next to a process group runs in
         # thread-local mode, FlowNet.compute_flow_and_conf), on its own stream -- also for data-parallel ranks on RCCL
         # (tests/test_rccl_gpu.py: bit-identical to the single-process trainer next to RCCL's collectives).  Only the gloo
@@ -648,7 +657,7 @@ class Vid2VidTrainer:
 
     def image_losses(self, real_B, fake_B, fake_B_raw, real_A, real_B_prev, fake_B_prev, flow, weight, flow_ref, conf_ref):
         o = self.opt
-        L = {}
+        L = _LossDict()
         wF, wT = o["lambda_F"] / (2 ** (self.n_scales - 1)), o["lambda_T"]
         imgvec = None
         if o["fused_losses"]:
@@ -685,7 +694,7 @@ class Vid2VidTrainer:
             dvec, gvec = self._fused_D_terms(pred_real, [pred_fake, pred_raw])
             L["D_real"], L["D_fake"] = dvec.unbind(0)
             L["G_GAN"], L["G_GAN_Feat"] = gvec.unbind(0)
-            self._loss_vecs = {id(L): (imgvec, dvec, gvec)}
+            L.vecs = (imgvec, dvec, gvec)
             return L
         d_real, d_fake, g_gan, g_fm = self._loss_D(self.netD, real_in, fake_in, pred_real, pred_fake)
         d_real2, d_fake2, g_gan2, g_fm2 = self._loss_D(self.netD, real_in, raw_in, pred_real, pred_raw)
@@ -704,8 +713,8 @@ class Vid2VidTrainer:
             pred_fake, pred_real = self._batched_D(self.netD_T[s], [fake_in, real_in], (2, 1), (1, 0))
             if self.opt["fused_losses"]:
                 dvec, gvec = self._fused_D_terms(pred_real, [pred_fake])
-                LT = dict(zip(("D_T_real", "D_T_fake", "G_T_GAN", "G_T_GAN_Feat"), tuple(dvec.unbind(0)) + tuple(gvec.unbind(0))))
-                self.__dict__.setdefault("_loss_vecs", {})[id(LT)] = (None, dvec, gvec)
+                LT = _LossDict(zip(("D_T_real", "D_T_fake", "G_T_GAN", "G_T_GAN_Feat"), tuple(dvec.unbind(0)) + tuple(gvec.unbind(0))))
+                LT.vecs = (None, dvec, gvec)
                 return LT
             d_real, d_fake, g_gan, g_fm = self._loss_D(self.netD_T[s], real_in, fake_in, pred_real, pred_fake)
         else:
@@ -840,11 +849,10 @@ class Vid2VidTrainer:
     def get_losses(self, L, LT):
         """Vid2VidModelD.get_losses (discriminator.py:236-248): ``L`` the image-loss dict, ``LT`` the list of temporal
         dicts of the active temporal scales.  Returns (loss_G, loss_D, [loss_D_T per active scale]).
-        Dicts that came out of the fused loss kernels carry their terms as vectors (``_loss_vecs``, keyed by dict identity):
+        Dicts that came out of the fused loss kernels carry their terms as vectors (``_LossDict.vecs``):
         the totals are then one concatenation + one sum for loss_G and one sum per discriminator -- not ~45 scalar adds
         forward and as many select / add nodes backward."""
-        vecs = getattr(self, "_loss_vecs", {})
-        mine = [vecs.get(id(d)) for d in [L] + list(LT)]
+        mine = [getattr(d, "vecs", None) for d in [L] + list(LT)]
         if all(v is not None for v in mine) and mine[0][0] is not None:
             imgvec, dvec, gvec = mine[0]
             g_parts = [imgvec, gvec] + [m[2] for m in mine[1:]]
@@ -887,11 +895,23 @@ class Vid2VidTrainer:
                 self._backward_done = torch.cuda.Event()
             self._backward_done.record()
         with autograd.backward_flags(d_nets if shared else [], autograd.SKIP_INPUT_GRAD):
-            loss_D.backward(inputs=self.grads_D.params if shared else None)
-            self.grads_D.all_reduce_async(self.world)
-            for s, ld in enumerate(loss_D_T):
-                ld.backward(inputs=self.grads_DT[s].params if shared else None)
-                self.grads_DT[s].all_reduce_async(self.world)
+            if self.d_streams and shared and loss_D_T:
+                # one pass over the three disjoint graphs: every node runs on the stream of its forward, so the
+                # discriminators' passes overlap as their forwards did (separate backward() calls would each end with
+                # the calling stream waiting for the pass, i.e. one discriminator after the other)
+                params = list(self.grads_D.params)
+                for s in range(len(loss_D_T)):
+                    params += list(self.grads_DT[s].params)
+                torch.autograd.backward([loss_D] + list(loss_D_T), inputs=params)
+                self.grads_D.all_reduce_async(self.world)
+                for s in range(len(loss_D_T)):
+                    self.grads_DT[s].all_reduce_async(self.world)
+            else:
+                loss_D.backward(inputs=self.grads_D.params if shared else None)
+                self.grads_D.all_reduce_async(self.world)
+                for s, ld in enumerate(loss_D_T):
+                    ld.backward(inputs=self.grads_DT[s].params if shared else None)
+                    self.grads_DT[s].all_reduce_async(self.world)
 
     def optimizer_steps(self, n_temporal):
         """The three ``optimizer.step()`` of train_vid2vid.py:104-111, then one launch refreshing every packed weight."""
@@ -945,11 +965,32 @@ class Vid2VidTrainer:
         flat = lambda t: t.reshape((-1,) + tuple(t.shape[2:]))  # noqa: E731
         if SC.ENABLED:      # the losses read FlowNet2's results on this stream
             SC.consumed(flow_ref, "reference flow (FlowNet2 replay)"), SC.consumed(conf_ref, "flow confidence (FlowNet2 replay)")
-        L = self.image_losses(flat(real_B), flat(fake_B), flat(fake_B_raw), flat(real_A), flat(real_B_prev), flat(fbp),
-                              flat(flow), flat(weight), flat(flow_ref), flat(conf_ref))
-        rb_s, fb_s, fl_s, cf_s = self.skipped_frames(rb_s, extra_flows, fake_B, flow_ref, conf_ref)
-        active = [s for s in range(self.t_scales) if rb_s[s] is not None]
-        LT = [self.temporal_losses(s, rb_s[s], fb_s[s], fl_s[s], cf_s[s]) for s in active]
+        if self.d_streams:
+            # The temporal discriminators first, each on its own stream (they wait for what the main stream has queued so
+            # far: the generator and the frame bookkeeping), then the image discriminator on the main stream: four
+            # independent networks of small layers side by side instead of one after the other.  The streams are joined
+            # before the totals; the backward passes follow the forward streams (autograd), see backward_passes.
+            from .networks import _Branch
+            rb_s, fb_s, fl_s, cf_s = self.skipped_frames(rb_s, extra_flows, fake_B, flow_ref, conf_ref)
+            active = [s for s in range(self.t_scales) if rb_s[s] is not None]
+            LT, joins = [], []
+            for s in active:
+                br = _Branch(rb_s[s], fb_s[s], fl_s[s], cf_s[s], slot=16 + s, force=True)
+                with br:
+                    lt = self.temporal_losses(s, rb_s[s], fb_s[s], fl_s[s], cf_s[s])
+                LT.append(lt)
+                joins.append((br, lt))
+            L = self.image_losses(flat(real_B), flat(fake_B), flat(fake_B_raw), flat(real_A), flat(real_B_prev), flat(fbp),
+                                  flat(flow), flat(weight), flat(flow_ref), flat(conf_ref))
+            for br, lt in joins:
+                vec = getattr(lt, "vecs", None)
+                br.join(*(list(lt.values()) + ([v for v in vec if v is not None] if vec else [])))
+        else:
+            L = self.image_losses(flat(real_B), flat(fake_B), flat(fake_B_raw), flat(real_A), flat(real_B_prev), flat(fbp),
+                                  flat(flow), flat(weight), flat(flow_ref), flat(conf_ref))
+            rb_s, fb_s, fl_s, cf_s = self.skipped_frames(rb_s, extra_flows, fake_B, flow_ref, conf_ref)
+            active = [s for s in range(self.t_scales) if rb_s[s] is not None]
+            LT = [self.temporal_losses(s, rb_s[s], fb_s[s], fl_s[s], cf_s[s]) for s in active]
         loss_G, loss_D, loss_D_T = self.get_losses(L, LT)
         self.backward_passes(loss_G, loss_D, loss_D_T)
         self.optimizer_steps(len(loss_D_T))

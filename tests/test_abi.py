@@ -44,6 +44,51 @@ def test_bindings_cover_the_header(built_lib):
     assert handle.ir2rgb_version().startswith(b"ir2rgb_hip")
 
 
+def test_fastcall_bindings_cover_the_prototypes_and_agree_with_ctypes(built_lib):
+    """ir2rgb_amd/fastbind.py: the CPython fastcall bindings are generated from _lib.PROTOTYPES (which the test above holds
+    against the header), built next to the library, current (signature of the prototypes they were generated from), and
+    hand back what the ctypes functions do -- checked on host-only entry points and on argument validation that returns
+    before any launch (no GPU here)."""
+    import ctypes
+    import torch
+    from ir2rgb_amd import conv as C, fastbind
+    assert os.path.exists(fastbind.so_path())
+    lib = _lib.lib()
+    fast, handle = lib.fast_module, lib.ctypes_handle
+    assert fast is not None and fast.SIGNATURE == fastbind.generate()[1]
+    covered = set(fastbind.wrappable())
+    assert covered == {n for n in _lib.PROTOTYPES if hasattr(fast, n)}
+    # everything but the three entry points that return strings or write through int* is covered
+    assert set(_lib.PROTOTYPES) - covered == {"ir2rgb_version", "ir2rgb_conv2d_kernel_name", "ir2rgb_correlation_out_shape",
+                                              "ir2rgb_conv2d_pack_batch_build"}
+    for name in covered:
+        assert getattr(lib, name) is getattr(fast, name)
+    d = C.make_desc((1, 1024, 32, 64), 1024, 3, 1, 1, C.PAD_REFLECT, torch.bfloat16)
+    assert d is C.make_desc((1, 1024, 32, 64), 1024, 3, 1, 1, C.PAD_REFLECT, torch.bfloat16) and d._addr == ctypes.addressof(d)
+    for fn in ("ir2rgb_conv2d_stats_rows", "ir2rgb_conv2d_fwd_workspace_bytes", "ir2rgb_conv2d_wgrad_workspace_elems",
+               "ir2rgb_conv2d_packed_weight_elems"):
+        want = getattr(handle, fn)(ctypes.byref(d))
+        assert getattr(fast, fn)(d) == want                        # descriptor object (_addr)
+        assert getattr(fast, fn)(d._addr) == want                  # plain address
+        assert getattr(fast, fn)(ctypes.byref(d)) == want          # ctypes reference (slow path)
+    assert fast.ir2rgb_bn_bwd_blocks(2048, 1024) == handle.ir2rgb_bn_bwd_blocks(2048, 1024) > 0
+    assert fast.ir2rgb_head_finish_bwd_rows(1, 64, 128) == handle.ir2rgb_head_finish_bwd_rows(1, 64, 128)
+    t = torch.zeros(64)
+    p = t.data_ptr()
+    # invalid arguments are refused by the library before anything is launched: same code through both bindings
+    args = (p, p, p, p, p, p, p, p, p, p, 100, 63, 0, 1, None)
+    assert fast.ir2rgb_bn_bwd(*args) == handle.ir2rgb_bn_bwd(*args) == -1
+    assert fast.ir2rgb_bn_bwd(ctypes.c_void_p(p), *args[1:]) == -1
+    fargs = (None, 0, 0, 1, None, None, None, None, None, 0.1, 1e-5, None, None, None, None, 1, 0, None)
+    assert fast.ir2rgb_bn_finalize_ex(*fargs) == handle.ir2rgb_bn_finalize_ex(*fargs) == -1
+    with pytest.raises(TypeError, match="takes 15 arguments"):
+        fast.ir2rgb_bn_bwd(p, p)
+    with pytest.raises(TypeError):
+        fast.ir2rgb_bn_bwd("x", *args[1:])
+    with pytest.raises(OverflowError):
+        fast.ir2rgb_bn_bwd(*args[:11], 1 << 40, 0, 1, None)
+
+
 def test_out_shape_matches_oracle(built_lib):
     from ir2rgb_amd.ext import correlation_cuda
     from oracle import ops

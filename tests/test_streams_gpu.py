@@ -147,3 +147,35 @@ def test_sixteen_training_windows_under_the_stream_check(dev):
         torch.cuda.synchronize()
     finally:
         SC.disable()
+
+
+def test_discriminator_streams_change_nothing_but_the_schedule(dev):
+    """The image discriminator's scales and the temporal discriminators on their own HIP streams (forward; the backward
+    passes follow through autograd) against the one-stream trainer: same kernels on the same operands, so the first window's
+    loss terms agree to the order in which the engine adds the three discriminators' gradient contributions of a generated
+    frame (the streams change the order the graph is built in), later windows to what training makes of such a difference
+    -- and two runs WITH the streams agree bit for bit, losses and parameters."""
+    from ir2rgb_amd import vid2vid as V
+    A, B = V.synthetic_sequence(14, 64, 128, 5, dev)
+
+    def run(streams):
+        tr = V.Vid2VidTrainer(dev, seed=0, first_layer_gen_filters=64, gen_blocks=2, resident_inputs=True,
+                              discriminator_streams=streams)
+        assert tr.d_streams == streams and getattr(tr.netD, "scale_streams", False) == streams
+        outs = [tr.train_window(A[:, w:w + 3], B[:, w:w + 3]) for w in range(12)]
+        torch.cuda.synchronize()
+        params = torch.cat([p.detach().reshape(-1) for m in tr.netG + [tr.netD] + tr.netD_T for p in m.parameters()])
+        return [{k: float(v) for k, v in o.items()} for o in outs], params
+
+    on1, p1 = run(True)
+    on2, p2 = run(True)
+    assert on1 == on2 and torch.equal(p1, p2), "two runs with discriminator streams differ"
+    off, p0 = run(False)
+    assert set(on1[-1]) == set(off[-1]) and any(k.startswith("D_T") for k in off[-1])
+    # the first window differs by summation order only; later ones by what twelve adversarial updates make of that
+    # (measured: 4e-3 on the D loss by window 8), so the bound loosens with the window and ends as a sanity check
+    dev_by_window = [max(abs(a[k] - b[k]) / (abs(b[k]) + 1e-3) for k in b) for a, b in zip(on1, off)]
+    assert dev_by_window[0] <= 1e-4, dev_by_window
+    assert max(dev_by_window[:3]) <= 5e-3, dev_by_window
+    assert max(dev_by_window) <= 0.2, dev_by_window
+    assert all(v == v and abs(v) < 1e6 for o in on1 for v in o.values())

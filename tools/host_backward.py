@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ir2rgb_amd import vid2vid as V, autograd as A, losses as LS, conv as C, layers as L
 dev = torch.device("cuda:0")
-tr = V.Vid2VidTrainer(dev, n_scales_spatial=2)
+tr = V.Vid2VidTrainer(dev, n_scales_spatial=2, resident_inputs=True)
 Aa, B = V.synthetic_sequence(30, 512, 1024, 1234, dev)
 for i in range(14):
     tr.train_window(Aa[:, i:i + 3], B[:, i:i + 3])
