@@ -219,7 +219,7 @@ class _Branch:
                                                                           getattr(owner, "branch_streams_training", False)))
         else:
             on = bool(force) and BRANCH_STREAMS != "0"
-        self.enabled = on and bool(self.inputs) and self.inputs[0].is_cuda and not torch.cuda.is_current_stream_capturing()
+        self.enabled = on and bool(self.inputs) and self.inputs[0].is_cuda      # (also inside a HIP-graph capture: the fork / join is captured)
         self.slot = slot
         self.ctx = None
 
