@@ -129,9 +129,18 @@ def lib():
         ns.ctypes_handle = handle
         ns.fast_module = fast
         for name in PROTOTYPES:
-            setattr(ns, name, getattr(fast, name, None) or getattr(handle, name))
+            setattr(ns, name, getattr(fast, name, None) or (getattr(handle, name) if fast is not None else _tensor_shim(getattr(handle, name))))
         _lib = ns
     return _lib
+
+
+def _tensor_shim(fn):
+    """ctypes function that, like the fastcall wrappers, takes tensors where pointers go (IR2RGB_FASTBIND=0 / extension
+    not built: the slow, reference binding)."""
+    def call(*args):
+        return fn(*[a.data_ptr() if hasattr(a, "data_ptr") else a for a in args])
+    call.__name__ = getattr(fn, "__name__", "ir2rgb_entry")
+    return call
 
 
 class _Entry:
@@ -173,14 +182,19 @@ class _NullCtx:
 
 
 _NULL = _NullCtx()
+_GET_DEVICE = None
 
 
 def on_device(tensor):
     """Context that makes the tensor's device current -- a no-op (no Python-level device switch) in the
     one-process-per-GPU deployment where it already is."""
-    import torch
-    if tensor.device.index == torch.cuda.current_device():
+    global _GET_DEVICE
+    if _GET_DEVICE is None:
+        import torch
+        _GET_DEVICE = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
+    if tensor.device.index == _GET_DEVICE():
         return _NULL
+    import torch
     return torch.cuda.device_of(tensor)
 
 

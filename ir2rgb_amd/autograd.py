@@ -24,12 +24,14 @@ from . import _lib
 from . import conv as C
 from . import layers as L
 from . import streamcheck as SC
+from . import stageplan
 
 _DT = {torch.bfloat16: 1, torch.float16: 2}
 _ADJ_DESCS = {}      # adjoint descriptors of strided convolutions (conv_dgrad), one object per geometry
 
 
 def _p(t):
+
     # (a plain int: accepted by the fastcall bindings and by ctypes' c_void_p parameters alike; a c_void_p object per
     # argument cost 0.75 us, ten of them per launch)
     return t.data_ptr() if t is not None else 0
@@ -66,7 +68,7 @@ def bn_bwd(gz, y, scale, shift, mean, invstd, act, out=None, params=None):
         ppartial = buf.data_ptr() + 8 * ch
     gy = out if out is not None else torch.empty_like(y, memory_format=torch.channels_last)
     with _lib.on_device(y):
-        rc = lib.ir2rgb_bn_bwd(_p(gz), _p(y), _p(scale), _p(shift), _p(mean), _p(invstd), _p(gy), _p(dgamma), _p(dbeta),
+        rc = lib.ir2rgb_bn_bwd(gz, y, scale, shift, mean, invstd, gy, dgamma, dbeta,
                                ppartial, npix, ch, act, _DT[y.dtype], _lib.current_stream(y))
     _lib.check(rc, "bn_bwd")
     return gy, dgamma, dbeta
@@ -81,7 +83,7 @@ def thin_grad_expand(gz, dtype):
     g8 = C.empty_nhwc(n, 8, h, w, dtype, gz.device)
     dbias = torch.empty(cout, dtype=torch.float32, device=gz.device)
     with _lib.on_device(gz):
-        rc = _lib.lib().ir2rgb_thin_grad_expand(_p(gz), _p(g64), _p(g8), _p(dbias), n, cout, h, w, _DT[dtype],
+        rc = _lib.lib().ir2rgb_thin_grad_expand(gz, g64, g8, dbias, n, cout, h, w, _DT[dtype],
                                                 _lib.current_stream(gz))
     _lib.check(rc, "thin_grad_expand")
     return g64, g8, dbias
@@ -93,7 +95,7 @@ def fold_reflect(dxpad, pad_h, pad_w=None):
     h, w = hp - 2 * pad_h, wp - 2 * pad_w
     dx = C.empty_nhwc(n, ch, h, w, dxpad.dtype, dxpad.device)
     with _lib.on_device(dxpad):
-        rc = _lib.lib().ir2rgb_fold_reflect(_p(dxpad), _p(dx), n, h, w, ch, pad_h, pad_w, _DT[dxpad.dtype],
+        rc = _lib.lib().ir2rgb_fold_reflect(dxpad, dx, n, h, w, ch, pad_h, pad_w, _DT[dxpad.dtype],
                                             _lib.current_stream(dxpad))
     _lib.check(rc, "fold_reflect")
     return dx
@@ -103,7 +105,7 @@ def xexpand_bwd(dxe, cin, w, kw, stride_w, pad_w, pad_mode):
     n, _, h, wout = dxe.shape
     din = torch.empty((n, cin, h, w), dtype=torch.float32, device=dxe.device)
     with _lib.on_device(dxe):
-        rc = _lib.lib().ir2rgb_xexpand_bwd(_p(dxe), _p(din), n, cin, h, w, wout, kw, stride_w, pad_w, pad_mode,
+        rc = _lib.lib().ir2rgb_xexpand_bwd(dxe, din, n, cin, h, w, wout, kw, stride_w, pad_w, pad_mode,
                                            _DT[dxe.dtype], _lib.current_stream(dxe))
     _lib.check(rc, "xexpand_bwd")
     return din
@@ -393,6 +395,10 @@ class ConvStageFn(Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, res1, res2, spec, conv, bn):
+        plan = stageplan.lookup(x, spec, conv, bn, FUSED_BN)
+        if plan is not None:        # the plain stage, host work precomputed (ir2rgb_amd/stageplan.py): same launches
+            return plan.forward(ctx, x, bias, res1, res2, conv, bn)
+        ctx.plan = None
         dt = spec["dtype"]
         first = spec["first"]
         cout, cin = conv.out_channels, conv.in_channels
@@ -473,8 +479,19 @@ class ConvStageFn(Function):
 
     @staticmethod
     def backward(ctx, gz):
-        spec, conv = ctx.spec, ctx.conv
-        xin, y, scale, shift, mean, invstd = ctx.saved_tensors
+        plan = ctx.plan
+        if plan is not None:
+            conv = ctx.conv
+            if not getattr(conv, "_ir2rgb_bwd", 0) and getattr(conv, "_ir2rgb_active", None) is None and not SC.ENABLED:
+                return plan.backward(ctx, gz)
+            # backward flags on a planned stage (a discriminator run without sample groups): the general code below
+            xin, y, vec = ctx.saved_tensors
+            scale, shift, mean, invstd = vec.unbind(0)
+            spec = plan.spec
+            ctx.wfn, ctx.frozen, ctx.x_shape, ctx.has_bn = None, False, plan.x_shape, True
+        else:
+            spec, conv = ctx.spec, ctx.conv
+            xin, y, scale, shift, mean, invstd = ctx.saved_tensors
         hdt = xin.dtype
         pad_fn = wfn = ctx.wfn
         cout, cin = conv.out_channels, conv.in_channels
@@ -642,7 +659,7 @@ class HeadFn(Function):
         for i, a in enumerate(acts):
             packed_acts |= (a & 15) << (4 * i)
         with _lib.on_device(feat):
-            rc = _lib.lib().ir2rgb_head_finish_bwd(_p(gout), _p(out), _p(dT), _p(dbias), _p(partial), n, h, w, cout, kh, CT, kh // 2,
+            rc = _lib.lib().ir2rgb_head_finish_bwd(gout, out, dT, dbias, partial, n, h, w, cout, kh, CT, kh // 2,
                                                    packed_acts, float(mul), _DT[feat.dtype], _lib.current_stream(feat))
         _lib.check(rc, "head_finish_bwd")
         spec = dict(k=(1, kw), stride=(1, 1), pad=(0, kw // 2), pad_mode=C.PAD_REFLECT, transposed=False)
@@ -699,8 +716,8 @@ class WarpBlendFn(Function):
         graw, gflow, gw = torch.empty_like(raw), torch.empty_like(flow), torch.empty_like(weight)
         n, _, h, w = raw.shape
         with _lib.on_device(raw):
-            rc = _lib.lib().ir2rgb_warp_blend_bwd(_p(gout), _p(raw), _p(prev), _p(flow), _p(weight), _p(graw), _p(gflow),
-                                                  _p(gw), n, prev.shape[1], h, w, _lib.current_stream(raw))
+            rc = _lib.lib().ir2rgb_warp_blend_bwd(gout, raw, prev, flow, weight, graw, gflow,
+                                                  gw, n, prev.shape[1], h, w, _lib.current_stream(raw))
         _lib.check(rc, "warp_blend_bwd")
         gprev = None
         if ctx.needs_input_grad[1]:
@@ -729,7 +746,7 @@ class AvgPool3s2Fn(Function):
         ctx.shape = tuple(x.shape)
         y = torch.empty(tuple(x.shape[:-2]) + ((h - 1) // 2 + 1, (w - 1) // 2 + 1), dtype=torch.float32, device=x.device)
         with _lib.on_device(x):
-            rc = _lib.lib().ir2rgb_avgpool3s2(_p(x), _p(y), x.numel() // (h * w), h, w, 0, _lib.current_stream(x))
+            rc = _lib.lib().ir2rgb_avgpool3s2(x, y, x.numel() // (h * w), h, w, 0, _lib.current_stream(x))
         _lib.check(rc, "avgpool3s2")
         return y
 
@@ -739,7 +756,7 @@ class AvgPool3s2Fn(Function):
         gx = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
         h, w = ctx.shape[-2:]
         with _lib.on_device(g):
-            rc = _lib.lib().ir2rgb_avgpool3s2(_p(g), _p(gx), gx.numel() // (h * w), h, w, 1, _lib.current_stream(g))
+            rc = _lib.lib().ir2rgb_avgpool3s2(g, gx, gx.numel() // (h * w), h, w, 1, _lib.current_stream(g))
         _lib.check(rc, "avgpool3s2 backward")
         return gx
 

@@ -20,6 +20,7 @@ ACT_NONE, ACT_LEAKY02 = 0, 1
 
 
 def _p(t):
+
     # (a plain int: accepted by the fastcall bindings and by ctypes' c_void_p parameters alike; a c_void_p object per
     # argument cost 0.75 us, ten of them per launch)
     return t.data_ptr() if t is not None else 0
@@ -123,7 +124,7 @@ class PackBatch:
 
     def run(self):
         with _lib.on_device(self.table):
-            rc = _lib.lib().ir2rgb_conv2d_pack_batch_run(_p(self.table), self.nentries, self.nblocks, self.dtype,
+            rc = _lib.lib().ir2rgb_conv2d_pack_batch_run(self.table, self.nentries, self.nblocks, self.dtype,
                                                          _lib.current_stream(self.table))
         _lib.check(rc, "conv2d_pack_batch_run")
 
@@ -140,7 +141,7 @@ def pack_weight(desc, weight, adjoint=False):
     packed = torch.empty(n, dtype=dt, device=weight.device)
     with _lib.on_device(weight):
         fn = lib.ir2rgb_conv2d_pack_weight_adjoint if adjoint else lib.ir2rgb_conv2d_pack_weight
-        rc = fn(desc, _p(weight), _p(packed), _lib.current_stream(weight))
+        rc = fn(desc, weight, packed, _lib.current_stream(weight))
     _lib.check(rc, "conv2d_pack_weight")
     return packed
 
@@ -245,7 +246,7 @@ def conv2d_fwd(desc, x, wpacked, bias=None, want_stats=False, out=None):
     with _lib.on_device(x):
         ws, ws_bytes = _fwd_workspace(desc, x)
         tok = _prof_begin(desc)
-        rc = _lib.lib().ir2rgb_conv2d_fwd_ws(desc, _p(x), _p(wpacked), _p(bias), _p(y), _p(stats), _p(ws), ws_bytes,
+        rc = _lib.lib().ir2rgb_conv2d_fwd_ws(desc, x, wpacked, bias, y, stats, ws, ws_bytes,
                                              _lib.current_stream(x))
     _lib.check(rc, "conv2d_fwd")
     if tok is not None:
@@ -282,7 +283,7 @@ def conv2d_wgrad(desc, x, gy, out=None, accumulate=False):
     with _lib.on_device(x):
         fn = lib.ir2rgb_conv2d_wgrad_acc if accumulate else lib.ir2rgb_conv2d_wgrad
         tok = _prof_begin(desc, "wgrad") if PROFILE is not None else None
-        rc = fn(desc, _p(x), _p(gy), _p(dw), _p(ws), _lib.current_stream(x))
+        rc = fn(desc, x, gy, dw, ws, _lib.current_stream(x))
         if tok is not None:
             _prof_end(tok, desc, "conv_wgrad")
     _lib.check(rc, "conv2d_wgrad")
@@ -300,7 +301,7 @@ def conv2d_fwd_view(desc, xbuf, wpacked, bias, ybuf, stats=None):
         raise ValueError("conv2d_fwd_view: GPU tensors only (no CPU fallback)")
     tok = _prof_begin(desc)
     with _lib.on_device(xbuf):
-        rc = _lib.lib().ir2rgb_conv2d_fwd(desc, _p(xbuf), _p(wpacked), _p(bias), _p(ybuf), _p(stats),
+        rc = _lib.lib().ir2rgb_conv2d_fwd(desc, xbuf, wpacked, bias, ybuf, stats,
                                           _lib.current_stream(xbuf))
     _lib.check(rc, "conv2d_fwd")
     if tok is not None:

@@ -17,6 +17,7 @@ _f32 = torch.float32
 
 
 def _p(t):
+
     return t.data_ptr()
 
 
@@ -45,7 +46,7 @@ class correlation_cuda:
             raise ValueError("correlation: empty output for these parameters")
         output.resize_(N, oc, oh, ow)
         with _lib.on_device(input1):
-            rc = _lib.lib().ir2rgb_correlation_fwd(_p(input1), _p(input2), _p(output), N, C, H, W, pad_size,
+            rc = _lib.lib().ir2rgb_correlation_fwd(input1, input2, output, N, C, H, W, pad_size,
                                                    kernel_size, max_displacement, stride1, stride2,
                                                    _lib.current_stream(input1))
         _lib.check(rc, "correlation_cuda.forward")
@@ -64,8 +65,8 @@ class correlation_cuda:
         gradInput1.resize_(N, C, H, W)
         gradInput2.resize_(N, C, H, W)
         with _lib.on_device(input1):
-            rc = _lib.lib().ir2rgb_correlation_bwd(_p(input1), _p(input2), _p(gradOutput), _p(gradInput1),
-                                                   _p(gradInput2), N, C, H, W, pad_size, kernel_size,
+            rc = _lib.lib().ir2rgb_correlation_bwd(input1, input2, gradOutput, gradInput1,
+                                                   gradInput2, N, C, H, W, pad_size, kernel_size,
                                                    max_displacement, stride1, stride2, _lib.current_stream(input1))
         _lib.check(rc, "correlation_cuda.backward")
         return 1
@@ -89,7 +90,7 @@ class resample2d_cuda:
         if tuple(output.shape) != (N, C, H, W):
             raise ValueError("resample2d: output has the wrong shape")
         with _lib.on_device(input1):
-            rc = _lib.lib().ir2rgb_resample2d_fwd(_p(input1), _p(input2), _p(output), N, C, H, W, kernel_size,
+            rc = _lib.lib().ir2rgb_resample2d_fwd(input1, input2, output, N, C, H, W, kernel_size,
                                                   _lib.current_stream(input1))
         _lib.check(rc, "resample2d_cuda.forward")
         return 1
@@ -99,8 +100,8 @@ class resample2d_cuda:
         N, C, H, W = resample2d_cuda._shapes(input1, input2)
         _lib.require_device(gradOutput, gradInput1, gradInput2, dtype=_f32)
         with _lib.on_device(input1):
-            rc = _lib.lib().ir2rgb_resample2d_bwd(_p(input1), _p(input2), _p(gradOutput), _p(gradInput1),
-                                                  _p(gradInput2), N, C, H, W, kernel_size,
+            rc = _lib.lib().ir2rgb_resample2d_bwd(input1, input2, gradOutput, gradInput1,
+                                                  gradInput2, N, C, H, W, kernel_size,
                                                   _lib.current_stream(input1))
         _lib.check(rc, "resample2d_cuda.backward")
         return 1
@@ -114,7 +115,7 @@ class channelnorm_cuda:
         if tuple(output.shape) != (N, 1, H, W):
             raise ValueError("channelnorm: output has the wrong shape")
         with _lib.on_device(input1):
-            rc = _lib.lib().ir2rgb_channelnorm_fwd(_p(input1), _p(output), N, C, H, W, norm_deg,
+            rc = _lib.lib().ir2rgb_channelnorm_fwd(input1, output, N, C, H, W, norm_deg,
                                                    _lib.current_stream(input1))
         _lib.check(rc, "channelnorm_cuda.forward")
         return 1
@@ -124,7 +125,7 @@ class channelnorm_cuda:
         _lib.require_device(input1, output, gradOutput, gradInput1, dtype=_f32)
         N, C, H, W = input1.shape
         with _lib.on_device(input1):
-            rc = _lib.lib().ir2rgb_channelnorm_bwd(_p(input1), _p(output), _p(gradOutput), _p(gradInput1), N, C, H, W,
+            rc = _lib.lib().ir2rgb_channelnorm_bwd(input1, output, gradOutput, gradInput1, N, C, H, W,
                                                    norm_deg, _lib.current_stream(input1))
         _lib.check(rc, "channelnorm_cuda.backward")
         return 1
@@ -142,8 +143,8 @@ def warp_diff_norm(img1, img2, flow, want_warped=True, want_diff=True, want_norm
     norm = img2.new_empty(N, 1, H, W) if want_norm else None
     null = 0
     with _lib.on_device(img1):
-        rc = _lib.lib().ir2rgb_warp_diff_norm_fwd(_p(img1), _p(img2), _p(flow), _p(warped) if want_warped else null,
-                                                  _p(diff) if want_diff else null, _p(norm) if want_norm else null,
+        rc = _lib.lib().ir2rgb_warp_diff_norm_fwd(img1, img2, flow, warped if want_warped else null,
+                                                  diff if want_diff else null, norm if want_norm else null,
                                                   N, C, H, W, _lib.current_stream(img1))
     _lib.check(rc, "warp_diff_norm")
     return warped, diff, norm

@@ -27,6 +27,7 @@ _DT = {torch.bfloat16: 1, torch.float16: 2}
 
 
 def _p(t):
+
     # (a plain int: accepted by the fastcall bindings and by ctypes' c_void_p parameters alike; a c_void_p object per
     # argument cost 0.75 us, ten of them per launch)
     return t.data_ptr() if t is not None else 0
@@ -142,7 +143,7 @@ def put_nchw(x_nchw, yv, act=0):
     x = x_nchw.float().contiguous()
     n, c, h, w = x.shape
     with _lib.on_device(x):
-        rc = _lib.lib().ir2rgb_nchw_f32_to_nhwc_half_slice(_p(x), _p(yv.buf), n, c, h, w, yv.ld, yv.off, act,
+        rc = _lib.lib().ir2rgb_nchw_f32_to_nhwc_half_slice(x, yv.buf, n, c, h, w, yv.ld, yv.off, act,
                                                            _DT[yv.buf.dtype], _lib.current_stream(x))
     _lib.check(rc, "nchw_f32_to_nhwc_half_slice")
 
@@ -160,7 +161,7 @@ def corr_nhwc(mod, av, bv, yv, slope):
     n = av.n
     h, w = av.hw
     with _lib.on_device(av.buf):
-        rc = _lib.lib().ir2rgb_correlation_nhwc_half(_p(av.buf), av.ld, av.off, _p(bv.buf), bv.ld, bv.off, _p(yv.buf), 1, yv.ld,
+        rc = _lib.lib().ir2rgb_correlation_nhwc_half(av.buf, av.ld, av.off, bv.buf, bv.ld, bv.off, yv.buf, 1, yv.ld,
                                                      yv.off, float(slope), n, av.ch, h, w, _DT[av.buf.dtype],
                                                      _lib.current_stream(av.buf))
     if rc == -2:        # IR2RGB_ENOSUP
@@ -173,7 +174,7 @@ def flow_up(flow, mod, yv):
     """ConvTranspose2d(2,2,4,2,1) of a 2-channel fp32 flow, written into a 2-channel slice of ``yv.buf``."""
     n, _, h, w = flow.shape
     with _lib.on_device(flow):
-        rc = _lib.lib().ir2rgb_flow_upsample_slice(_p(flow), _p(mod.weight), _p(mod.bias), _p(yv.buf), n, h, w, yv.ld, yv.off,
+        rc = _lib.lib().ir2rgb_flow_upsample_slice(flow, mod.weight, mod.bias, yv.buf, n, h, w, yv.ld, yv.off,
                                                    _DT[yv.buf.dtype], _lib.current_stream(flow))
     _lib.check(rc, "flow_upsample_slice")
 

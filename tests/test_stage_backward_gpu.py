@@ -178,6 +178,64 @@ def test_fold_reflect_and_xexpand_adjoints(dev):
         assert abs(lhs.item() - rhs.item()) <= 5e-3 * abs(lhs.item()) + 0.5, (kw, lhs.item(), rhs.item())
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [
+    # Cin, H, W, Cout, k, stride, pad, pad_mode name, transposed, opad, act, residual
+    (256, 16, 64, 256, 3, 1, 1, "PAD_REFLECT", False, 0, "ACT_RELU", True),      # residual block (in-place reflect adjoint, fused BN)
+    (128, 32, 64, 128, 3, 1, 1, "PAD_REFLECT", False, 0, "ACT_NONE", True),
+    (64, 64, 128, 128, 3, 2, 1, "PAD_ZERO", False, 0, "ACT_RELU", False),        # down-sampling (strided adjoint)
+    (128, 16, 32, 64, 3, 2, 1, "PAD_ZERO", True, 1, "ACT_RELU", False),          # up-sampling (sub-pixel classes)
+    (64, 70, 200, 128, 4, 2, 2, "PAD_ZERO", False, 0, "ACT_LEAKY", False),       # discriminator layer, > 128 statistics rows
+    (64, 20, 24, 64, 7, 1, 3, "PAD_REFLECT", False, 0, "ACT_RELU", False),       # reflect 7x7: data gradient via the fold pass
+])
+def test_planned_stage_equals_the_general_stage(dev, dtype, case):
+    """ir2rgb_amd/stageplan.py (the plain stage with its host work cached) against ConvStageFn's general code: the same
+    library calls on the same arguments, so outputs, BatchNorm buffers and every gradient agree bit for bit -- two forwards
+    and backwards each (the second one hits the cached plan; the weight gradient accumulates in the kernel)."""
+    import copy
+    from ir2rgb_amd import autograd as A, conv as C, layers as L, stageplan
+    cin, h, w, cout, k, s, p, pm, tr, op, act, use_res = case
+    gen = torch.Generator().manual_seed(cin + h + k)
+    x0 = torch.randn(2, cin, h, w, generator=gen).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    conv0 = (torch.nn.ConvTranspose2d(cin, cout, k, s, p, output_padding=op) if tr else torch.nn.Conv2d(cin, cout, k, s, 0)).to(dev)
+    bn0 = torch.nn.BatchNorm2d(cout).to(dev)
+    with torch.no_grad():
+        bn0.weight.normal_(1.0, 0.2)
+        bn0.bias.normal_(0.0, 0.2)
+    results = []
+    for lean in (True, False):
+        stageplan.ENABLED = lean
+        try:
+            conv, bn = copy.deepcopy(conv0), copy.deepcopy(bn0)
+            outs = []
+            for rep in range(2):
+                x = x0.clone().requires_grad_(True)
+                res = None
+                kw = dict(stride=s, pad=p, transposed=tr, output_padding=op, training=True)
+                z = A.conv_stage(x, conv, bn, getattr(L, act), getattr(C, pm), dtype, **kw)
+                if use_res:
+                    res = torch.randn(z.shape, generator=torch.Generator().manual_seed(rep)).to(dev).to(dtype).contiguous(
+                        memory_format=torch.channels_last).requires_grad_(True)
+                    z = A.conv_stage(x, conv, bn, getattr(L, act), getattr(C, pm), dtype, res1=res, **kw)
+                g = torch.randn(z.shape, generator=torch.Generator().manual_seed(7 + rep)).to(dev).to(dtype).contiguous(
+                    memory_format=torch.channels_last)
+                z.backward(g)
+                L.flush_bn_counters()
+                outs += [z.detach().clone(), x.grad.clone()] + ([res.grad.clone()] if res is not None else [])
+            outs += [conv.weight.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(), bn.running_mean.clone(),
+                     bn.running_var.clone(), bn.num_batches_tracked.clone()]
+            assert conv.bias.grad is None or not conv.bias.grad.any()
+            planned = any(v for v in conv.__dict__.get("_ir2rgb_plans", {}).values())
+            assert planned == lean
+            results.append(outs)
+        finally:
+            stageplan.ENABLED = True
+    assert len(results[0]) == len(results[1])
+    for i, (a, b) in enumerate(zip(*results)):
+        assert torch.equal(a, b), f"output {i} differs between the planned and the general stage"
+        assert torch.isfinite(a.float()).all()
+
+
 @pytest.mark.parametrize("case", [
     # Cin, W, KW, stride, pad, reflect
     (9, 300, 7, 1, 3, 1),       # the generators' 7-wide first layer: three 128-column tiles, ragged last one, both mirrors

@@ -8,7 +8,10 @@ dev = torch.device("cuda:0")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 tr = V.Vid2VidTrainer(dev, n_scales_spatial=2, resident_inputs=True)
 A, B = V.synthetic_sequence(n + 2, 512, 1024, 1234, dev)
+import gc
 for i in range(n):
+    if i == 14 and os.environ.get("GC_TUNE", "0") == "1":
+        gc.collect(); gc.freeze(); gc.set_threshold(50000, 20, 20)
     if i == n - 10:
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -5,14 +5,14 @@ import torch
 from torch.profiler import profile, ProfilerActivity
 from ir2rgb_amd import vid2vid as V
 dev = torch.device("cuda:0")
-tr = V.Vid2VidTrainer(dev, n_scales_spatial=2)
-A, B = V.synthetic_sequence(16, 512, 1024, 1234, dev)
-for i in range(9):
+tr = V.Vid2VidTrainer(dev, n_scales_spatial=2, resident_inputs=True)
+A, B = V.synthetic_sequence(24, 512, 1024, 1234, dev)
+for i in range(16):
     tr.train_window(A[:, i:i + 3], B[:, i:i + 3])
 torch.cuda.synchronize()
 print("warm", flush=True)
 with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU], with_stack=("--stack" in sys.argv)) as prof:
-    for i in range(9, 12):
+    for i in range(16, 19):
         tr.train_window(A[:, i:i + 3], B[:, i:i + 3])
     torch.cuda.synchronize()
 tab = prof.key_averages().table(sort_by="cuda_time_total", row_limit=45, max_name_column_width=70)
