@@ -46,6 +46,7 @@ DEFAULTS = dict(  # options/base_options.py, options/train_options.py (SURVEY se
     build_flow_net=True,  # False: trainer.flow_net is left None for the caller to set (tests plug a stand-in for FlowNet2)
     branch_streams_fine_scales=True,   # the finer spatial scales' generators run their two branches on two HIP streams, forward
     discriminator_streams=True,        # the image discriminator's scales and the temporal discriminators each on their own HIP stream (forward and, through autograd, backward): independent networks of small layers that fill a fraction of the chip one at a time
+    adam_stream=False,                 # the generators' Adam step on its own HIP stream beside the discriminators' backward passes: measured again in round 3 with the discriminators on their own streams, 26.9 ms per window against 26.3 without (round 1: 39.05 vs 38.8) -- off
                                        # and backward (the coarsest scale's kernels are what bench.py brackets: one stream)
 )
 
@@ -456,6 +457,8 @@ class Vid2VidTrainer:
         for g in self.netG[1:]:
             g.branch_streams_training = bool(o["branch_streams_fine_scales"]) and os.environ.get("IR2RGB_BRANCH_FINE", "1") != "0"
         self.d_streams = bool(o["discriminator_streams"]) and os.environ.get("IR2RGB_D_STREAMS", "1") != "0" and device.type == "cuda"
+        self.adam_stream_on = os.environ.get("IR2RGB_ADAM_STREAM", "1" if o["adam_stream"] else "0") != "0" and device.type == "cuda"
+        self._adam_stream, self._adam_pending = None, False
         self.netD.scale_streams = self.d_streams
         # FlowNet2 is replayed from a HIP graph in every configuration (a capture next to a process group runs in
         # thread-local mode, FlowNet.compute_flow_and_conf), on its own stream -- also for data-parallel ranks on RCCL
@@ -869,10 +872,11 @@ class Vid2VidTrainer:
             loss_D_T.append((lt["D_T_fake"] + lt["D_T_real"]) * 0.5)
         return loss_G, loss_D, loss_D_T
 
-    def backward_passes(self, loss_G, loss_D, loss_D_T, g_inputs=None):
+    def backward_passes(self, loss_G, loss_D, loss_D_T, g_inputs=None, early_adam=False):
         """The three ``loss.backward()`` of train_vid2vid.py:104-111 (zero_grad included); each optimizer's gradient
         all-reduce is issued as soon as its pass ends, so it overlaps the next pass.  ``g_inputs``: the tensors
-        the generator's pass differentiates with respect to (default: the generator parameters)."""
+        the generator's pass differentiates with respect to (default: the generator parameters).  ``early_adam`` (train_window):
+        the generators' optimizer step is issued right after their pass, on its own stream; optimizer_steps() then skips it."""
         self.grads_G.zero()
         self.grads_D.zero()
         for gdt in self.grads_DT:
@@ -894,6 +898,18 @@ class Vid2VidTrainer:
             if self._backward_done is None:
                 self._backward_done = torch.cuda.Event()
             self._backward_done.record()
+        if self.adam_stream_on and early_adam:
+            # The generators' optimizer step needs nothing but their finished pass: it starts here, on its own stream, beside
+            # the discriminators' backward passes (which never touch generator weights or gradients) -- 2 ms of pure HBM
+            # streaming next to small latency-bound launches.  optimizer_steps() joins it before the repack.
+            main = torch.cuda.current_stream(self.device)
+            if self._adam_stream is None:
+                self._adam_stream = torch.cuda.Stream(self.device)
+            self._adam_stream.wait_stream(main)
+            with torch.cuda.stream(self._adam_stream):
+                self.grads_G.wait()
+                self.optimizer_G.step()
+            self._adam_pending = True
         with autograd.backward_flags(d_nets if shared else [], autograd.SKIP_INPUT_GRAD):
             if self.d_streams and shared and loss_D_T:
                 # one pass over the three disjoint graphs: every node runs on the stream of its forward, so the
@@ -915,13 +931,18 @@ class Vid2VidTrainer:
 
     def optimizer_steps(self, n_temporal):
         """The three ``optimizer.step()`` of train_vid2vid.py:104-111, then one launch refreshing every packed weight."""
-        self.grads_G.wait()
-        self.optimizer_G.step()
+        if self._adam_pending:          # (issued by backward_passes on the Adam stream)
+            self._adam_pending = False
+        else:
+            self.grads_G.wait()
+            self.optimizer_G.step()
         self.grads_D.wait()
         self.optimizer_D.step()
         for s in range(n_temporal):
             self.grads_DT[s].wait()
             self.optimizer_D_T[s].step()
+        if self._adam_stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._adam_stream)
         if self.repacker is not None:
             self.repacker.run()          # every packed forward / data-gradient weight copy, one launch
 
@@ -992,7 +1013,7 @@ class Vid2VidTrainer:
             active = [s for s in range(self.t_scales) if rb_s[s] is not None]
             LT = [self.temporal_losses(s, rb_s[s], fb_s[s], fl_s[s], cf_s[s]) for s in active]
         loss_G, loss_D, loss_D_T = self.get_losses(L, LT)
-        self.backward_passes(loss_G, loss_D, loss_D_T)
+        self.backward_passes(loss_G, loss_D, loss_D_T, early_adam=True)
         self.optimizer_steps(len(loss_D_T))
         self.last_outputs = tuple(t.detach() for t in (fake_B, fake_B_raw, flow, weight))
         out = {"G": loss_G.detach(), "D": loss_D.detach()}
