@@ -190,6 +190,11 @@ import os as _os
 
 BRANCH_STREAMS = _os.environ.get("IR2RGB_BRANCH_STREAMS", "auto")   # "auto" | "1" | "0" | set by branch_streams()
 _SIDE_STREAMS = {}
+# side-stream slot of the image discriminator's scale 1 (scale i: + i - 1).  Default 0 = the generators' second-branch
+# stream, which is idle while the discriminators run, so that fewer streams compete for the device's four hardware queues
+# (26.2-27.0 ms per window against 26.4-27.9 with a stream of its own, same box; GPU_MAX_HW_QUEUES=6 / 8 made the window
+# 45 % SLOWER: the streams are fitted to the queues, not the other way round).
+_D_SCALE_SLOT0 = int(_os.environ.get("IR2RGB_D_SCALE_SLOT", "0"))
 
 
 @_contextlib.contextmanager
@@ -526,7 +531,7 @@ class MultiScaleDiscriminator(nn.Module):
                 xs.append(A.avg_pool3s2(xs[-1]))
             pending = []
             for i in range(1, self.num_D):
-                br = _Branch(xs[i], slot=8 + i, force=True)
+                br = _Branch(xs[i], slot=_D_SCALE_SLOT0 + i - 1, force=True)
                 with br:
                     outs = _run_patchgan(self._groups(self.num_D - 1 - i), xs[i], self.compute_dtype, self.training,
                                          sample_groups, group_order)

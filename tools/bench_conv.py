@@ -8,6 +8,7 @@ SHAPES = [  # name, Cin, H, W, Cout, k, stride, pad, pad_mode, transposed, opad
     ("res3x3_1024@64x128", 1024, 64, 128, 1024, 3, 1, 1, 1, False, 0),
     ("res3x3_1024@32x64", 1024, 32, 64, 1024, 3, 1, 1, 1, False, 0),
     ("local3x3_128@256x512", 128, 256, 512, 128, 3, 1, 1, 1, False, 0),
+    ("local3x3_128@512x1024", 128, 512, 1024, 128, 3, 1, 1, 1, False, 0),
     ("down3x3s2_512->1024@128x256", 512, 128, 256, 1024, 3, 2, 1, 0, False, 0),
     ("down3x3s2_128->256@512x1024", 128, 512, 1024, 256, 3, 2, 1, 0, False, 0),
     ("up3x3T_1024->512@64x128", 1024, 64, 128, 512, 3, 2, 1, 0, True, 1),
