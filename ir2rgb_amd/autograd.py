@@ -452,8 +452,42 @@ class ConvStageFn(Function):
                 vec = torch.empty((4, G, cout_p), dtype=torch.float32, device=y.device)
                 scale, shift, mean, invstd = vec[0], vec[1], vec[2], vec[3]
                 reps = L._STAT_UPDATES        # layers.repeated_forward: an int, or one count per group
+                if not ctx.frozen and bnp is bn and not SC.ENABLED and spec["training"]:
+                    # the same per-group launches as the loop below, addressed by offset: no slices, no per-group wrappers
+                    # (3 groups x 12 BatchNorm stages per window: ~7 tensor views and ~10 us of Python per group)
+                    lib, stream = _lib.lib(), _lib.current_stream(y)
+                    _, pw, pb, prm, prv, has_rm, momentum, eps, trs = L._bn_ptrs(bn)
+                    track = trs and has_rm
+                    py, pz, ps, pv = y.data_ptr(), z.data_ptr(), stats.data_ptr(), vec.data_ptr()
+                    npix_g = count // G
+                    per_y, per_s, c4 = npix_g * cout_p * y.element_size(), rg * 2 * cout_p * 4, cout_p * 4
+                    gc4, act_, dtc = G * c4, spec["act"], _DT[y.dtype]
+                    fuse_g = fused and rg <= L.FUSED_BN_MAX_ROWS
+                    for g in (spec.get("group_order") or range(G)):
+                        r = reps[g] if isinstance(reps, tuple) else reps
+                        sc = pv + g * c4
+                        if fuse_g:
+                            rc = lib.ir2rgb_bn_finalize_apply(ps + g * per_s, rg, cout_p, npix_g, pw, pb, bias, prm if track else None,
+                                                              prv if track else None, momentum, eps, sc, sc + gc4, sc + 2 * gc4,
+                                                              sc + 3 * gc4, r, py + g * per_y, None, None, pz + g * per_y, npix_g,
+                                                              act_, dtc, stream)
+                            if rc:
+                                _lib.check(rc, "bn_finalize_apply")
+                        else:
+                            rc = lib.ir2rgb_bn_finalize_ex(ps + g * per_s, rg, cout_p, npix_g, pw, pb, bias, prm if track else None,
+                                                           prv if track else None, momentum, eps, sc, sc + gc4, sc + 2 * gc4,
+                                                           sc + 3 * gc4, r, 0, stream)
+                            if rc:
+                                _lib.check(rc, "bn_finalize")
+                            rc = lib.ir2rgb_bn_apply(py + g * per_y, sc, sc + gc4, None, None, pz + g * per_y, npix_g, cout_p, act_, dtc,
+                                                     stream)
+                            if rc:
+                                _lib.check(rc, "bn_apply")
+                        if track and bn.num_batches_tracked is not None:
+                            L._PENDING_COUNTERS.append((bn.num_batches_tracked, r))
+                    G = 0       # (done: the loop below is empty)
                 try:
-                    for g in (spec.get("group_order") or range(G)):      # (the order the running statistics advance in)
+                    for g in ((spec.get("group_order") or range(G)) if G else ()):      # (the order the running statistics advance in)
                         L._STAT_UPDATES = reps[g] if isinstance(reps, tuple) else reps
                         yg, zg = y[g * ng:(g + 1) * ng], z[g * ng:(g + 1) * ng]
                         sg = None if ctx.frozen else stats[g * rg:(g + 1) * rg]
@@ -520,6 +554,29 @@ class ConvStageFn(Function):
             act = spec["act"] | (16 if ctx.frozen else 0)
             if scale.dim() == 1:
                 gy, dgamma, dbeta = bn_bwd(gz, y, scale, shift, mean, invstd, act)
+            elif not ctx.frozen and not SC.ENABLED and gz.is_contiguous(memory_format=torch.channels_last):
+                # sample groups, addressed by offset (the launches of the loop in the next branch, without its slices and
+                # per-group wrappers; one partial-row region serves all groups: same stream, one group after the other)
+                G = scale.shape[0]
+                ng, ch = y.shape[0] // G, y.shape[1]
+                npix_g = ng * y.shape[2] * y.shape[3]
+                lib, stream = _lib.lib(), _lib.current_stream(y)
+                nblk = lib.ir2rgb_bn_bwd_blocks(npix_g, ch)
+                if nblk < 0:
+                    _lib.check(nblk, "bn_bwd_blocks")
+                gy = torch.empty_like(y, memory_format=torch.channels_last)
+                buf = torch.empty((nblk * 2 + 5) * ch, dtype=torch.float32, device=y.device)
+                dgamma, dbeta = buf[:ch], buf[ch:2 * ch]
+                pb_, c4 = buf.data_ptr(), ch * 4
+                per = npix_g * ch * y.element_size()
+                pg, py_, pgy = gz.data_ptr(), y.data_ptr(), gy.data_ptr()
+                psc, psh, pmu, piv = scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr()
+                dtc = _DT[y.dtype]
+                for g in range(G):
+                    rc = lib.ir2rgb_bn_bwd(pg + g * per, py_ + g * per, psc + g * c4, psh + g * c4, pmu + g * c4, piv + g * c4,
+                                           pgy + g * per, pb_, pb_ + c4, pb_ + 2 * c4, npix_g, ch, act | (32 if g else 0), dtc, stream)
+                    if rc:
+                        _lib.check(rc, "bn_bwd")
             else:                       # sample groups: per-group BatchNorm backward into the batch's gradient tensor
                 G = scale.shape[0]
                 ng = y.shape[0] // G
