@@ -510,6 +510,162 @@ conv_wgrad3x3_kernel(const uint16_t *__restrict__ U, const uint16_t *__restrict_
         }
 }
 
+// ----------------------------------------------------------------------------------------
+// k x 1 / 1 x k convolutions at 64-channel tiles (the generators' separable 7x7 first layers and heads, the
+// discriminators' 4x1 stride-2 first layers: full-resolution tensors, tiny weights): ALL taps of a 64 (a) x 64 (b) tile
+// in one workgroup, as conv_wgrad3x3_kernel does for 3x3.  The one-tap kernel (even with two taps per workgroup)
+// streams the gradient tensor once per tap pair and multiplies a half-empty 128-row tile: 202 us for a 7x1 layer at
+// 64 channels and 512x1024, where both tensors are 27 us of HBM time and the products 12 us of MFMA time.
+//
+// A K-step = one 64-pixel segment of one output row: the gradient tile (64 px x 64 ch, rows 0..63 of the stage) and
+// the NTY x (64 + NTX - 1) pixel input patch behind it (rows 64..); tap (ty, tx) is the patch read at row offset
+// ty * PW + tx.  LDS layout, swizzle and the transposed fragment reads are conv_wgrad3x3_kernel's (128-byte rows).
+// 512 threads: waves 0..3 multiply (16 b-channels each, all 64 a-channels: NT x 4 accumulator tiles), waves 4..7
+// stage the next K-step by LDS-DMA into the other of two stages (the multipliers never issue a DMA, so the
+// compiler's conservative vmcnt waits around the transposed reads cost nothing).  Output: per-split slabs
+// [split][tap][a][b], summed by the finish pass in a fixed order -- no atomics.
+// ----------------------------------------------------------------------------------------
+struct WgradLineGeom {
+    int N, Hq, Wq, Hv, Wv, Ca, Cb;
+    int stride_y, pad_mode, dy0, dx0;
+    int segs, ksteps, ksplit, per;     // K-steps = N * Hq * segs, `per` of them per split
+    unsigned u_bytes, v_bytes;
+};
+
+template <int DT, int NTY, int NTX>
+__global__ void __launch_bounds__(512, 1)
+conv_wgrad_line_kernel(const uint16_t *__restrict__ U, const uint16_t *__restrict__ V, float *__restrict__ D,
+                       const WgradLineGeom g) {
+    constexpr int NT = NTY * NTX, PW = 64 + NTX - 1, PR = NTY * PW;
+    constexpr int NID = 8 + (PR + 7) / 8;          // 1-KB DMA instructions (8 rows each) per K-step: 8 gradient, the rest patch
+    constexpr int J = (NID + 3) / 4;               // ... per loader wave
+    constexpr int STAGE = NID * 1024;
+    static_assert(2 * STAGE <= 160 * 1024 - 1024, "two stages must fit the LDS");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave8 >= 4;
+    const int wave = wave8 & 3;
+    const int ntb = g.Cb >> 6, nta = g.Ca >> 6;
+    int bid = blockIdx.x;
+    const int tb = bid % ntb; bid /= ntb;
+    const int ta = bid % nta;
+    const int split = bid / nta;
+    const int a0 = ta * 64, b0 = tb * 64;
+    const int kbeg = split * g.per, kend = min(g.ksteps, kbeg + g.per);   // (the host leaves no split empty)
+    auto fsw = [](int r) { return ((r >> 1) & 1) | (((r >> 3) & 1) << 1); };
+
+    if (loader) {
+        const rsrc_t ru = make_rsrc(U, g.u_bytes), rv = make_rsrc(V, g.v_bytes);
+        const int rin = lane >> 3, sl = lane & 7;
+        const unsigned ca2 = (unsigned)g.Ca * 2u, cb2 = (unsigned)g.Cb * 2u;
+        // (row, seg) of the next K-step to issue, advanced incrementally; row = n * Hq + qy
+        int is_row = kbeg / g.segs, is_seg = kbeg - is_row * g.segs, is_n = is_row / g.Hq, is_y = is_row - is_n * g.Hq;
+        auto issue = [&](int buf) {
+            unsigned char *dst = smem + buf * STAGE + wave * 1024;
+            const int x0 = is_seg * 64;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int id = wave + 4 * j;           // wave-uniform
+                if (id >= NID) break;
+                unsigned off = WG_OOB;
+                if (id < 8) {                           // gradient rows: output pixels x0 + r of this row
+                    const int r = id * 8 + rin;
+                    const int chunk = (((sl >> 1) ^ fsw(r)) << 1) | (sl & 1);
+                    if (x0 + r < g.Wq)
+                        off = ((unsigned)is_row * (unsigned)g.Wq + (unsigned)(x0 + r)) * ca2 + (unsigned)(a0 + chunk * 8) * 2u;
+                    dma16(ru, off, dst + 4096 * j);
+                } else {                                // patch rows: tap row pr, column pxl
+                    const int R = (id - 8) * 8 + rin;
+                    const int pr = R / PW, pxl = R - pr * PW;
+                    const int chunk = (((sl >> 1) ^ fsw(R)) << 1) | (sl & 1);
+                    int iy = is_y * g.stride_y + g.dy0 + pr, ix = x0 + pxl + g.dx0;
+                    const bool inb = ((unsigned)iy < (unsigned)g.Hv) & ((unsigned)ix < (unsigned)g.Wv);
+                    iy = g.pad_mode ? reflect1(iy, g.Hv) : iy;
+                    ix = g.pad_mode ? reflect1(ix, g.Wv) : ix;
+                    // (reflection of a column far right of a ragged last segment can still leave the row: such patch
+                    // columns only ever meet gradient rows that are zero, any in-range address will do)
+                    ix = min(max(ix, 0), g.Wv - 1);
+                    iy = min(max(iy, 0), g.Hv - 1);
+                    if (R < PR && (g.pad_mode || inb))
+                        off = (((unsigned)is_n * (unsigned)g.Hv + (unsigned)iy) * (unsigned)g.Wv + (unsigned)ix) * cb2 +
+                              (unsigned)(b0 + chunk * 8) * 2u;
+                    dma16(rv, off, dst + 4096 * j);
+                }
+            }
+            if (++is_seg == g.segs) {
+                is_seg = 0;
+                ++is_row;
+                if (++is_y == g.Hq) { is_y = 0; ++is_n; }
+            }
+        };
+        issue(0);
+        int lb = 0;
+        for (int ks = kbeg; ks < kend; ++ks) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // step ks has landed
+            __builtin_amdgcn_s_barrier();                         // ... and step ks-1 has been consumed
+            if (ks + 1 < kend) issue(lb ^ 1);
+            lb ^= 1;
+        }
+        return;
+    }
+
+    // ---------------- multiplying waves ----------------
+    const int grp = lane >> 4, l15 = lane & 15;
+    const int qd = l15 >> 2, pp = l15 & 3;
+    const int sub = (pp >> 1) * 16 + (pp & 1) * 8;
+    const int rl = 8 * grp + qd;                       // row of this lane inside a 32-row K block (h = 0)
+    int aoff[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) aoff[mi] = rl * 128 + ((mi ^ fsw(rl)) << 5) + sub;
+    int boff[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int R = (t / NTX) * PW + (t % NTX) + rl + 4 * h;
+            boff[t][h] = 8192 + R * 128 + ((wave ^ fsw(R)) << 5) + sub;
+        }
+    f32x4 acc[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[t][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int buf = 0;
+    for (int ks = kbeg; ks < kend; ++ks) {
+        __builtin_amdgcn_s_barrier();
+        const unsigned char *tile = smem + buf * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            s16x8 a[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const s16x4 lo = lds_tr(tile + aoff[mi] + kk * 4096), hi = lds_tr(tile + aoff[mi] + kk * 4096 + 512);
+                a[mi] = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const s16x4 lo = lds_tr(tile + boff[t][0] + kk * 4096), hi = lds_tr(tile + boff[t][1] + kk * 4096);
+                const s16x8 b = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) acc[t][mi] = Mfma<DT>::run(a[mi], b, acc[t][mi]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the stage have returned before it is handed back
+        buf ^= 1;
+    }
+    // ---------------- epilogue: D[split][tap][a][b] ----------------
+    const int b = b0 + wave * 16 + l15;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        float *Dt = D + ((long)split * NT + t) * g.Ca * g.Cb;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Dt[(long)(a0 + mi * 16 + grp * 4 + r) * g.Cb + b] = acc[t][mi][r];
+    }
+}
+
 // out[i] = sum_split D[split][i]   (slabs already in the torch layout)
 __global__ void __launch_bounds__(256)
 wgrad_sum_kernel(const float4 *__restrict__ D, float4 *__restrict__ out, long n4, int nsplit) {
@@ -589,9 +745,34 @@ wgrad_finish_tiled_kernel(const float *__restrict__ D, float *__restrict__ out, 
     }
 }
 
+// Many splits (the line kernel: up to 256): one workgroup per (64 (a, b) pairs, tap); wave w sums the splits w, w+4, ...
+// (64 coalesced loads each instead of 256 dependent ones per thread), the four partial sums are added in wave order.
+__global__ void __launch_bounds__(256)
+wgrad_finish_wide_kernel(const float *__restrict__ D, float *__restrict__ out, long AB, int ntaps, int nsplit, int acc) {
+    __shared__ float part[4][64];
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6, tap = blockIdx.y;
+    const long ab = blockIdx.x * 64L + l;
+    const long slab = (long)ntaps * AB;
+    float s = 0.f;
+    if (ab < AB) {
+        const float *p = D + (long)tap * AB + ab;
+#pragma unroll 8
+        for (int k = w; k < nsplit; k += 4) s += p[k * slab];
+    }
+    part[w][l] = s;
+    __syncthreads();
+    if (w == 0 && ab < AB) {
+        const float v = ((part[0][l] + part[1][l]) + part[2][l]) + part[3][l];
+        const long o = ab * ntaps + tap;
+        out[o] = acc ? out[o] + v : v;
+    }
+}
+
 static void launch_wgrad_finish(const float *D, float *out, int Ca, int Cb, int ntaps, int nsplit, hipStream_t s, int acc = 0) {
     const long AB = (long)Ca * Cb, elems = AB * ntaps;
-    if (ntaps <= WF_MAX_TAPS && (AB + 63) / 64 <= 0x7fffffffL)
+    if (nsplit > 64 && (AB + 63) / 64 <= 0x7fffffffL && ntaps <= 65535)
+        wgrad_finish_wide_kernel<<<dim3((unsigned)((AB + 63) / 64), (unsigned)ntaps), 256, 0, s>>>(D, out, AB, ntaps, nsplit, acc);
+    else if (ntaps <= WF_MAX_TAPS && (AB + 63) / 64 <= 0x7fffffffL)
         wgrad_finish_tiled_kernel<<<(unsigned)((AB + 63) / 64), 256, 0, s>>>(D, out, AB, ntaps, nsplit, acc);
     else
         wgrad_finish_kernel<<<stream_grid(elems, 256), 256, 0, s>>>(D, out, Ca, Cb, ntaps, nsplit, elems, acc);
@@ -643,6 +824,48 @@ static int plan(const ir2rgb_conv_desc *d, WgradGeom *g) {
     return IR2RGB_OK;
 }
 
+// k x 1 / 1 x k layers on conv_wgrad_line_kernel: 7x1, 1x7 (stride 1 along the taps' axis is not required: the taps run
+// along y for k x 1, where the stride enters the row index) and the stride-2 4x1; 64-multiples on both channel axes.
+static bool plan_line(const ir2rgb_conv_desc *d, WgradLineGeom *g) {
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("IR2RGB_WGRAD_LINE"); on = e ? atoi(e) : 1; }
+    if (!on || d->transposed || (d->Cin % 64) || (d->Cout % 64) || d->stride_w != 1) return false;
+    const bool k7x1 = d->kh == 7 && d->kw == 1, k1x7 = d->kh == 1 && d->kw == 7, k4x1 = d->kh == 4 && d->kw == 1;
+    if (!(k7x1 || k1x7 || k4x1)) return false;
+    // (7x1 restages its 7-row patch for every a-tile and is bound by the LDS fill rate: with two a-tiles the one-tap kernel
+    // is as fast -- 44.7 vs 48.2 us at 64 -> 128 channels, 256x512 -- so only the one-tile case comes here)
+    if (k7x1 && d->Cout != 64) return false;
+    if (d->pad_mode != 0 && d->pad_mode != 1) return false;
+    if (d->pad_mode == 1 && (d->pad_h >= d->Hin || d->pad_w >= d->Win)) return false;
+    const long Q = (long)d->N * d->Hout * d->Wout, Pv = (long)d->N * d->Hin * d->Win;
+    if (Q * d->Cout * 2 >= (1L << 31) || Pv * d->Cin * 2 >= (1L << 31)) return false;
+    *g = WgradLineGeom{};
+    g->N = d->N; g->Hq = d->Hout; g->Wq = d->Wout; g->Hv = d->Hin; g->Wv = d->Win; g->Ca = d->Cout; g->Cb = d->Cin;
+    g->stride_y = d->stride_h; g->pad_mode = d->pad_mode; g->dy0 = -d->pad_h; g->dx0 = -d->pad_w;
+    g->segs = (d->Wout + 63) / 64;
+    const long ksteps = (long)d->N * d->Hout * g->segs;
+    if (ksteps >= (1L << 30)) return false;
+    g->ksteps = (int)ksteps;
+    // one workgroup per CU: ~256 workgroups, at least 8 K-steps each, no empty split
+    const long tiles = (long)(d->Cout / 64) * (d->Cin / 64);
+    long ks = (256 + tiles - 1) / tiles;
+    if (ks > ksteps / 8) ks = ksteps / 8;
+    if (ks < 1) ks = 1;
+    if (ks > 256) ks = 256;
+    g->per = (int)((ksteps + ks - 1) / ks);
+    g->ksplit = (int)((ksteps + g->per - 1) / g->per);
+    g->u_bytes = (unsigned)(Q * d->Cout * 2); g->v_bytes = (unsigned)(Pv * d->Cin * 2);
+    return true;
+}
+
+template <int DT>
+static void launch_line(const ir2rgb_conv_desc *d, const WgradLineGeom &g, const uint16_t *U, const uint16_t *V, float *D, hipStream_t s) {
+    const unsigned grid = (unsigned)((long)g.ksplit * (g.Ca / 64) * (g.Cb / 64));
+    if (d->kh == 7) conv_wgrad_line_kernel<DT, 7, 1><<<grid, 512, 0, s>>>(U, V, D, g);
+    else if (d->kw == 7) conv_wgrad_line_kernel<DT, 1, 7><<<grid, 512, 0, s>>>(U, V, D, g);
+    else conv_wgrad_line_kernel<DT, 4, 1><<<grid, 512, 0, s>>>(U, V, D, g);
+}
+
 static bool use_wgrad9() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("IR2RGB_WGRAD9"); v = e ? atoi(e) : 1; }
@@ -655,6 +878,8 @@ extern "C" long ir2rgb_conv2d_wgrad_workspace_elems(const ir2rgb_conv_desc *d) {
     if (rc) return rc;
     Wgrad9Geom g9;
     if (use_wgrad9() && plan9(d, &g9)) return g9.ksplit > 1 ? (long)g9.ksplit * 9 * g9.Ca * g9.Cb : 4;
+    WgradLineGeom gl;
+    if (plan_line(d, &gl)) return (long)gl.ksplit * d->kh * d->kw * gl.Ca * gl.Cb;
     return (long)g.ksplit * d->kh * d->kw * g.Ca * g.Cb;
 }
 
@@ -675,7 +900,9 @@ extern "C" long ir2rgb_conv2d_wgrad_acc_workspace_elems(const ir2rgb_conv_desc *
     WgradGeom g;
     int rc = plan(d, &g);
     if (rc) return rc;
-    return (long)g.ksplit * d->kh * d->kw * g.Ca * g.Cb;       // always the one-tap kernel's slabs (see wgrad_impl)
+    WgradLineGeom gl;
+    if (plan_line(d, &gl)) return (long)gl.ksplit * d->kh * d->kw * gl.Ca * gl.Cb;
+    return (long)g.ksplit * d->kh * d->kw * g.Ca * g.Cb;       // else always the one-tap kernel's slabs (see wgrad_impl)
 }
 
 static int wgrad_impl(const ir2rgb_conv_desc *d, const void *x, const void *gy, float *dw, float *workspace, void *stream,
@@ -701,6 +928,13 @@ static int wgrad_impl(const ir2rgb_conv_desc *d, const void *x, const void *gy, 
         return ir2rgb_launch_status();
     }
     const uint16_t *U = (const uint16_t *)(d->transposed ? x : gy), *V = (const uint16_t *)(d->transposed ? gy : x);
+    WgradLineGeom gl;
+    if (plan_line(d, &gl)) {        // k x 1 / 1 x k layers: all taps of a 64 x 64 tile per workgroup
+        if (d->dtype == IR2RGB_BF16) launch_line<IR2RGB_BF16>(d, gl, U, V, workspace, s);
+        else launch_line<IR2RGB_F16>(d, gl, U, V, workspace, s);
+        launch_wgrad_finish(workspace, dw, gl.Ca, gl.Cb, ntaps, gl.ksplit, s, acc);
+        return ir2rgb_launch_status();
+    }
     const unsigned grid = (unsigned)((long)g.ksplit * ((ntaps + g.tpb - 1) / g.tpb) * ((g.Ca + 127) / 128) * ((g.Cb + 127) / 128));
     static int split = -1;
     if (split < 0) { const char *e = getenv("IR2RGB_WGRAD_SPLIT"); split = e ? atoi(e) : 1; }

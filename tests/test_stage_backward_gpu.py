@@ -302,6 +302,50 @@ def test_wgrad_kernel_vs_torch(dev, dtype, case):
     assert _rel(dw, wr.grad) <= 2e-3, _rel(dw, wr.grad)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [
+    # N, Cin, H, W, Cout, (kh, kw), (sh, sw), (ph, pw), reflect, accumulate
+    (2, 64, 21, 130, 64, (7, 1), (1, 1), (3, 0), True, False),     # first-layer 7x1 pass: reflect along y, ragged third segment
+    (1, 64, 40, 64, 64, (7, 1), (1, 1), (3, 0), True, True),       # dw += (a second use of the weight)
+    (1, 64, 24, 64, 128, (4, 1), (2, 1), (2, 0), False, False),    # two a-tiles
+    (2, 64, 9, 200, 64, (1, 7), (1, 1), (0, 3), True, False),      # head 1x7 pass: reflect along x across segment borders
+    (1, 128, 12, 128, 64, (1, 7), (1, 1), (0, 3), True, False),    # two b-tiles (128-channel feature map)
+    (3, 64, 37, 65, 64, (4, 1), (2, 1), (2, 0), False, False),     # discriminator 4x1 stride 2, zero padding, odd sizes, 3 samples
+    (2, 64, 512, 66, 64, (4, 1), (2, 1), (2, 0), False, True),     # many K-steps: 256 splits, wide finish pass, accumulate
+    (1, 64, 6, 10, 64, (7, 1), (1, 1), (3, 0), True, False),       # fewer K-steps than splits could hold
+])
+def test_line_wgrad_kernel_vs_torch(dev, dtype, case):
+    """conv_wgrad_line_kernel (all taps of a k x 1 / 1 x k layer from one staged tile per 64 x 64 channel tile, per-split
+    slabs summed in a fixed order) vs torch's fp32 backward-filter on the same half-rounded operands, relative L2 <= 2e-3;
+    two calls agree bit for bit (no atomics)."""
+    from ir2rgb_amd import conv as C
+    n, cin, h, w, cout, k, s, p, reflect, accumulate = case
+    g = torch.Generator().manual_seed(cin + h + w)
+    x = torch.randn(n, cin, h, w, generator=g).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    desc = C.make_desc(tuple(x.shape), cout, k, s, p, C.PAD_REFLECT if reflect else C.PAD_ZERO, dtype)
+    gy = torch.randn(n, cout, desc.Hout, desc.Wout, generator=g).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    wr = torch.zeros((cout, cin) + k, device=dev, requires_grad=True)
+    xr = x.float()
+    if reflect:
+        xr = F.pad(xr, (p[1], p[1], p[0], p[0]), mode="reflect")
+        y = F.conv2d(xr, wr, None, s)
+    else:
+        y = F.conv2d(xr, wr, None, s, p)
+    (y * gy.float()).sum().backward()
+    if accumulate:
+        base = torch.randn(wr.shape, generator=g).to(dev)
+        dw = base.clone()
+        C.conv2d_wgrad(desc, x, gy, out=dw, accumulate=True)
+        dw2 = base.clone()
+        C.conv2d_wgrad(desc, x, gy, out=dw2, accumulate=True)
+        want = base + wr.grad
+    else:
+        dw, dw2, want = C.conv2d_wgrad(desc, x, gy), C.conv2d_wgrad(desc, x, gy), wr.grad
+    assert dw.shape == want.shape and torch.equal(dw, dw2)
+    assert _rel(dw - (base if accumulate else 0), wr.grad) <= 2e-3, _rel(dw - (base if accumulate else 0), wr.grad)
+    assert torch.allclose(dw, want, rtol=1e-2, atol=1e-2 * float(wr.grad.abs().max()))
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 1e-2), (torch.bfloat16, 4e-2)])
 def test_head_and_warp_blend_backward(dev, dtype, tol):
     """Separable 7x7 heads (tanh image head; flow*20 + sigmoid weight heads sharing one feature map) and
