@@ -1,6 +1,9 @@
+# Round-end evidence on a GPU box: the GPU test suite, smoke(), two bench.py runs and rocprofv3 kernel stats of the bench, the
+# training windows, the north-star graph forward and config 5 -> gpurun_out/evidence/ (copy what is to be judged into profiles/).
+# usage (from the repository root):  gpurun --timeout 1200 -- bash tools/collect_evidence.sh
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r3h; mkdir -p $O
+O=$R/gpurun_out/evidence; mkdir -p $O
 cd $R
 python -m pytest tests -m gpu -x -q > $O/gpu_tests.txt 2>&1 || { tail -40 $O/gpu_tests.txt; exit 1; }
 tail -2 $O/gpu_tests.txt
