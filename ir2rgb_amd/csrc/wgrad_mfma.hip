@@ -666,6 +666,146 @@ conv_wgrad_line_kernel(const uint16_t *__restrict__ U, const uint16_t *__restric
     }
 }
 
+// The k x 1 layers again, walking DOWN the image: consecutive K-steps are the same 64-pixel column segment of consecutive
+// output rows, whose NTY-row input patches overlap in all but SY rows.  The patch lives in a ring of NTY + SY row slots
+// (64 pixels x 128 B each) per column parity; a K-step stages its gradient segment and only the SY input rows that are
+// new (all NTY at the top of a column or of a split, into the OTHER parity's ring, so that the rows the multiplying waves
+// are reading are never touched).  conv_wgrad_line_kernel restaged the whole patch per step and ran at the LDS fill
+// rate: 7x1 at 64 channels, 512x1024: 85 us; here the operands enter the LDS once.
+template <int DT, int NTY, int SY>
+__global__ void __launch_bounds__(512, 1)
+conv_wgrad_col_kernel(const uint16_t *__restrict__ U, const uint16_t *__restrict__ V, float *__restrict__ D,
+                      const WgradLineGeom g) {
+    constexpr int RC = NTY + SY;                   // ring slots per column parity
+    constexpr int PATCH0 = 16384;                  // two 8-KB gradient buffers in front
+    constexpr int LDS = PATCH0 + 2 * RC * 8192;
+    constexpr int JMAX = (8 + NTY * 8 + 3) / 4;    // DMA instructions per loader wave of a priming step
+    static_assert(LDS <= 160 * 1024 - 1024, "ring must fit the LDS");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave8 >= 4;
+    const int wave = wave8 & 3;
+    const int ntb = g.Cb >> 6, nta = g.Ca >> 6;
+    int bid = blockIdx.x;
+    const int tb = bid % ntb; bid /= ntb;
+    const int ta = bid % nta;
+    const int split = bid / nta;
+    const int a0 = ta * 64, b0 = tb * 64;
+    const int kbeg = split * g.per, kend = min(g.ksteps, kbeg + g.per);   // K-step ks = (column = n * segs + seg, row y), y fastest
+    auto fsw = [](int r) { return ((r >> 1) & 1) | (((r >> 3) & 1) << 1); };
+
+    if (loader) {
+        const rsrc_t ru = make_rsrc(U, g.u_bytes), rv = make_rsrc(V, g.v_bytes);
+        const int rin = lane >> 3, sl = lane & 7;
+        const unsigned ca2 = (unsigned)g.Ca * 2u, cb2 = (unsigned)g.Cb * 2u;
+        int col = kbeg / g.Hq, y = kbeg - col * g.Hq, n = col / g.segs, seg = col - n * g.segs, ub = 0;
+        bool first = true;
+        auto issue = [&]() {
+            const bool prime = first || y == 0;
+            const int x0 = seg * 64, half = col & 1;
+            const int total = 8 + (prime ? NTY : SY) * 8;
+#pragma unroll
+            for (int j = 0; j < JMAX; ++j) {
+                const int id = wave + 4 * j;           // wave-uniform
+                if (id >= total) break;
+                unsigned off = WG_OOB;
+                if (id < 8) {                           // gradient pixels x0 + r of output row y
+                    const int r = id * 8 + rin;
+                    const int chunk = (((sl >> 1) ^ fsw(r)) << 1) | (sl & 1);
+                    if (x0 + r < g.Wq)
+                        off = (((unsigned)n * (unsigned)g.Hq + (unsigned)y) * (unsigned)g.Wq + (unsigned)(x0 + r)) * ca2 +
+                              (unsigned)(a0 + chunk * 8) * 2u;
+                    dma16(ru, off, smem + ub * 8192 + id * 1024);
+                } else {                                // input row y * SY + jt (virtual, before padding), pixels x0 + r
+                    const int q = id - 8;
+                    const int jt = (prime ? 0 : NTY - SY) + (q >> 3);
+                    const int r = (q & 7) * 8 + rin;
+                    const int chunk = (((sl >> 1) ^ fsw(r)) << 1) | (sl & 1);
+                    const int v = y * SY + jt;
+                    int iy = v + g.dy0;
+                    const int ix = x0 + r;
+                    const bool inb = ((unsigned)iy < (unsigned)g.Hv) & (ix < g.Wv);
+                    iy = g.pad_mode ? reflect1(iy, g.Hv) : iy;
+                    iy = min(max(iy, 0), g.Hv - 1);
+                    if (ix < g.Wv && (g.pad_mode || inb))
+                        off = (((unsigned)n * (unsigned)g.Hv + (unsigned)iy) * (unsigned)g.Wv + (unsigned)ix) * cb2 +
+                              (unsigned)(b0 + chunk * 8) * 2u;
+                    const int slot = half * RC + v % RC;
+                    dma16(rv, off, smem + PATCH0 + slot * 8192 + (q & 7) * 1024);
+                }
+            }
+            first = false;
+            ub ^= 1;
+            if (++y == g.Hq) {
+                y = 0;
+                ++col;
+                if (++seg == g.segs) { seg = 0; ++n; }
+            }
+        };
+        issue();
+        for (int ks = kbeg; ks < kend; ++ks) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // step ks has landed
+            __builtin_amdgcn_s_barrier();                         // ... and step ks-1 has been consumed
+            if (ks + 1 < kend) issue();
+        }
+        return;
+    }
+
+    // ---------------- multiplying waves ----------------
+    const int grp = lane >> 4, l15 = lane & 15;
+    const int qd = l15 >> 2, pp = l15 & 3;
+    const int sub = (pp >> 1) * 16 + (pp & 1) * 8;
+    const int rl = 8 * grp + qd;
+    int aoff[4], boffl[2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) aoff[mi] = rl * 128 + ((mi ^ fsw(rl)) << 5) + sub;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) boffl[h] = PATCH0 + (rl + 4 * h) * 128 + ((wave ^ fsw(rl + 4 * h)) << 5) + sub;
+    f32x4 acc[NTY][4];
+#pragma unroll
+    for (int t = 0; t < NTY; ++t)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[t][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int col = kbeg / g.Hq, y = kbeg - col * g.Hq, ub = 0;
+    for (int ks = kbeg; ks < kend; ++ks) {
+        __builtin_amdgcn_s_barrier();
+        const unsigned char *ut = smem + ub * 8192;
+        const int base = (col & 1) * RC, v0 = (y * SY) % RC;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            s16x8 a[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const s16x4 lo = lds_tr(ut + aoff[mi] + kk * 4096), hi = lds_tr(ut + aoff[mi] + kk * 4096 + 512);
+                a[mi] = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int t = 0; t < NTY; ++t) {
+                int slot = v0 + t;
+                slot = slot >= RC ? slot - RC : slot;
+                const unsigned char *pt = smem + (base + slot) * 8192 + kk * 4096;
+                const s16x4 lo = lds_tr(pt + boffl[0]), hi = lds_tr(pt + boffl[1]);
+                const s16x8 b = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) acc[t][mi] = Mfma<DT>::run(a[mi], b, acc[t][mi]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads have returned before the buffers are handed back
+        ub ^= 1;
+        if (++y == g.Hq) { y = 0; ++col; }
+    }
+    const int b = b0 + wave * 16 + l15;
+#pragma unroll
+    for (int t = 0; t < NTY; ++t) {
+        float *Dt = D + ((long)split * NTY + t) * g.Ca * g.Cb;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Dt[(long)(a0 + mi * 16 + grp * 4 + r) * g.Cb + b] = acc[t][mi][r];
+    }
+}
+
 // out[i] = sum_split D[split][i]   (slabs already in the torch layout)
 __global__ void __launch_bounds__(256)
 wgrad_sum_kernel(const float4 *__restrict__ D, float4 *__restrict__ out, long n4, int nsplit) {
@@ -832,9 +972,8 @@ static bool plan_line(const ir2rgb_conv_desc *d, WgradLineGeom *g) {
     if (!on || d->transposed || (d->Cin % 64) || (d->Cout % 64) || d->stride_w != 1) return false;
     const bool k7x1 = d->kh == 7 && d->kw == 1, k1x7 = d->kh == 1 && d->kw == 7, k4x1 = d->kh == 4 && d->kw == 1;
     if (!(k7x1 || k1x7 || k4x1)) return false;
-    // (7x1 restages its 7-row patch for every a-tile and is bound by the LDS fill rate: with two a-tiles the one-tap kernel
-    // is as fast -- 44.7 vs 48.2 us at 64 -> 128 channels, 256x512 -- so only the one-tile case comes here)
-    if (k7x1 && d->Cout != 64) return false;
+    if (k7x1 && d->pad_w != 0) return false;
+    if (k4x1 && d->pad_w != 0) return false;
     if (d->pad_mode != 0 && d->pad_mode != 1) return false;
     if (d->pad_mode == 1 && (d->pad_h >= d->Hin || d->pad_w >= d->Win)) return false;
     const long Q = (long)d->N * d->Hout * d->Wout, Pv = (long)d->N * d->Hin * d->Win;
@@ -861,7 +1000,11 @@ static bool plan_line(const ir2rgb_conv_desc *d, WgradLineGeom *g) {
 template <int DT>
 static void launch_line(const ir2rgb_conv_desc *d, const WgradLineGeom &g, const uint16_t *U, const uint16_t *V, float *D, hipStream_t s) {
     const unsigned grid = (unsigned)((long)g.ksplit * (g.Ca / 64) * (g.Cb / 64));
-    if (d->kh == 7) conv_wgrad_line_kernel<DT, 7, 1><<<grid, 512, 0, s>>>(U, V, D, g);
+    static int ring = -1;           // IR2RGB_WGRAD_RING=0: the k x 1 layers on the row-major line kernel (A/B measurements)
+    if (ring < 0) { const char *e = getenv("IR2RGB_WGRAD_RING"); ring = e ? atoi(e) : 1; }
+    if (d->kh == 7 && ring && d->stride_h == 1) conv_wgrad_col_kernel<DT, 7, 1><<<grid, 512, 0, s>>>(U, V, D, g);
+    else if (d->kh == 4 && ring && d->stride_h == 2) conv_wgrad_col_kernel<DT, 4, 2><<<grid, 512, 0, s>>>(U, V, D, g);
+    else if (d->kh == 7) conv_wgrad_line_kernel<DT, 7, 1><<<grid, 512, 0, s>>>(U, V, D, g);
     else if (d->kw == 7) conv_wgrad_line_kernel<DT, 1, 7><<<grid, 512, 0, s>>>(U, V, D, g);
     else conv_wgrad_line_kernel<DT, 4, 1><<<grid, 512, 0, s>>>(U, V, D, g);
 }
