@@ -150,6 +150,55 @@ def test_reflect_adjoint_stays_in_bounds(dev, name, dtype):
     assert ws_intact and torch.equal(gy.t, y0) and torch.equal(gs.t, s0) and gy.intact() and gs.intact()
 
 
+LINE_CASES = {
+    # name: (N, Cin, H, W, Cout, (kh, kw), (sh, sw), (ph, pw), reflect)  -- the layers of the round-3 kernels
+    "first7x1_reflect_ragged": (2, 64, 21, 130, 64, (7, 1), (1, 1), (3, 0), 1),     # conv7x1_col forward, conv_wgrad_col 7x1
+    "first7x1_two_cout_tiles": (1, 64, 13, 96, 128, (7, 1), (1, 1), (3, 0), 1),
+    "head1x7_wgrad": (2, 64, 9, 200, 64, (1, 7), (1, 1), (0, 3), 1),                # conv_wgrad_line 1x7
+    "d4x1_stride2": (3, 64, 37, 65, 64, (4, 1), (2, 1), (2, 0), 0),                 # conv_wgrad_col 4x1 stride 2
+}
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("name", list(LINE_CASES))
+def test_line_kernels_stay_in_bounds(dev, name, dtype):
+    """The k x 1 / 1 x k kernels of round 3 (column-tile forward, line / column weight gradients with up to 256 split
+    slabs and the wide finish pass): operands inside NaN guard bands, the weight-gradient workspace of EXACTLY
+    ir2rgb_conv2d_wgrad_workspace_elems and the destination inside canary bands, results bit-identical to plain tensors."""
+    from ir2rgb_amd import _lib
+    from ir2rgb_amd import conv as C
+    n, cin, h, w, cout, k, stride, pad, reflect = LINE_CASES[name]
+    gen = torch.Generator().manual_seed(len(name) + 3)
+    x = _nhwc(n, cin, h, w, dtype, dev, gen)
+    desc = C.make_desc(tuple(x.shape), cout, k, stride, pad, C.PAD_REFLECT if reflect else C.PAD_ZERO, dtype)
+    wt = (torch.randn((cout, cin) + k, generator=gen) * 0.05).to(dev)
+    wp = C.pack_weight(desc, wt)
+    gx, gw = Guarded(x, float("nan")), Guarded(wp, float("nan"))
+    y0, s0 = C.conv2d_fwd(desc, x, wp, None, want_stats=True)
+    gy = Guarded(y0, 7.0)
+    gy.t.zero_()
+    y1, s1 = C.conv2d_fwd(desc, gx.t, gw.t, None, want_stats=True, out=gy.t)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y1.float()).all() and torch.equal(y1, y0) and torch.equal(s1, s0)
+    assert gy.intact() and gx.intact() and gw.intact()
+    # weight gradient through the C ABI with a guarded workspace of exactly the declared size and a guarded destination
+    g = _nhwc(n, cout, y0.shape[2], y0.shape[3], dtype, dev, gen)
+    gg = Guarded(g, float("nan"))
+    dw0 = C.conv2d_wgrad(desc, x, g)
+    lib = _lib.lib()
+    nws = lib.ir2rgb_conv2d_wgrad_workspace_elems(desc)
+    assert nws > 0
+    ws = Guarded(torch.zeros(nws, device=dev), 5.0)
+    dst = Guarded(torch.zeros_like(dw0), 3.0)
+    rc = lib.ir2rgb_conv2d_wgrad(desc, gx.t, gg.t, dst.t, ws.t, _lib.current_stream(x))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dst.t, dw0) and torch.isfinite(dw0).all()
+    assert ws.intact(), "weight-gradient kernel wrote outside its workspace"
+    assert dst.intact(), "finish pass wrote outside the weight gradient"
+    assert gx.intact() and gg.intact()
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_batchnorm_kernels_stay_in_bounds(dev, dtype):
     from ir2rgb_amd import autograd as A
