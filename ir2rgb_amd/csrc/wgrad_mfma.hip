@@ -532,11 +532,17 @@ struct WgradLineGeom {
     unsigned u_bytes, v_bytes;
 };
 
-template <int DT, int NTY, int NTX>
+// SX = 2 (3x3 stride-2 layers, plain and transposed: the down- / up-samplers): output pixel i of a segment reads input
+// columns 2i + tx + const, i.e. every other pixel -- but the transposed fragment reads want the 32 pixels of a K block in
+// consecutive LDS rows.  So the patch is staged split by column parity: run (ty, parity) holds the columns
+// cb + 2 * idx + parity, idx = 0 .. PWp - 1, and tap (ty, tx) is run (ty, tx & 1) read from idx offset tx >> 1.
+template <int DT, int NTY, int NTX, int SX = 1>
 __global__ void __launch_bounds__(512, 1)
 conv_wgrad_line_kernel(const uint16_t *__restrict__ U, const uint16_t *__restrict__ V, float *__restrict__ D,
                        const WgradLineGeom g) {
-    constexpr int NT = NTY * NTX, PW = 64 + NTX - 1, PR = NTY * PW;
+    constexpr int NT = NTY * NTX;
+    constexpr int PW = SX == 2 ? 64 + ((NTX - 1) >> 1) : 64 + NTX - 1;     // pixels per patch run
+    constexpr int PR = NTY * (SX == 2 ? 2 : 1) * PW;
     constexpr int NID = 8 + (PR + 7) / 8;          // 1-KB DMA instructions (8 rows each) per K-step: 8 gradient, the rest patch
     constexpr int J = (NID + 3) / 4;               // ... per loader wave
     constexpr int STAGE = NID * 1024;
@@ -577,9 +583,11 @@ conv_wgrad_line_kernel(const uint16_t *__restrict__ U, const uint16_t *__restric
                     dma16(ru, off, dst + 4096 * j);
                 } else {                                // patch rows: tap row pr, column pxl
                     const int R = (id - 8) * 8 + rin;
-                    const int pr = R / PW, pxl = R - pr * PW;
+                    const int run = R / PW, pxl = R - run * PW;
+                    const int pr = SX == 2 ? run >> 1 : run;
                     const int chunk = (((sl >> 1) ^ fsw(R)) << 1) | (sl & 1);
-                    int iy = is_y * g.stride_y + g.dy0 + pr, ix = x0 + pxl + g.dx0;
+                    int iy = is_y * g.stride_y + g.dy0 + pr;
+                    int ix = SX == 2 ? 2 * x0 + g.dx0 + 2 * pxl + (run & 1) : x0 + pxl + g.dx0;
                     const bool inb = ((unsigned)iy < (unsigned)g.Hv) & ((unsigned)ix < (unsigned)g.Wv);
                     iy = g.pad_mode ? reflect1(iy, g.Hv) : iy;
                     ix = g.pad_mode ? reflect1(ix, g.Wv) : ix;
@@ -623,7 +631,8 @@ conv_wgrad_line_kernel(const uint16_t *__restrict__ U, const uint16_t *__restric
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int R = (t / NTX) * PW + (t % NTX) + rl + 4 * h;
+            const int ty = t / NTX, tx = t % NTX;
+            const int R = (SX == 2 ? (ty * 2 + (tx & 1)) * PW + (tx >> 1) : ty * PW + tx) + rl + 4 * h;
             boff[t][h] = 8192 + R * 128 + ((wave ^ fsw(R)) << 5) + sub;
         }
     f32x4 acc[NT][4];
@@ -969,31 +978,45 @@ static int plan(const ir2rgb_conv_desc *d, WgradGeom *g) {
 static bool plan_line(const ir2rgb_conv_desc *d, WgradLineGeom *g) {
     static int on = -1;
     if (on < 0) { const char *e = getenv("IR2RGB_WGRAD_LINE"); on = e ? atoi(e) : 1; }
-    if (!on || d->transposed || (d->Cin % 64) || (d->Cout % 64) || d->stride_w != 1) return false;
+    if (!on || (d->Cin % 64) || (d->Cout % 64)) return false;
+    static int s2 = -1;             // IR2RGB_WGRAD_S2=0: the stride-2 3x3 layers on the one-tap kernel (A/B measurements)
+    if (s2 < 0) { const char *e = getenv("IR2RGB_WGRAD_S2"); s2 = e ? atoi(e) : 1; }
+    // (measured against the one-tap kernel, us at the training sizes: 64->128 @512x1024 49 vs 60, 512->1024 @64x128 54 vs 60,
+    // 1024->512 transposed 53 vs 58, 128->64 transposed 49 vs 56 -- but 128->256 52 vs 43, 256->512 48 vs 43: every 64 x 64
+    // tile restages the 57-KB patch, which only pays at the two ends of the channel range; s2 = 2 forces it everywhere)
+    const long tl = (long)(d->Cout / 64) * (d->Cin / 64);
+    const bool k3s2 = s2 && d->kh == 3 && d->kw == 3 && d->stride_h == 2 && d->stride_w == 2 && d->pad_mode == 0 &&
+                      (s2 == 2 || tl <= 2 || tl >= 128);
     const bool k7x1 = d->kh == 7 && d->kw == 1, k1x7 = d->kh == 1 && d->kw == 7, k4x1 = d->kh == 4 && d->kw == 1;
-    if (!(k7x1 || k1x7 || k4x1)) return false;
+    if (!k3s2 && (d->transposed || d->stride_w != 1)) return false;
+    if (!(k7x1 || k1x7 || k4x1 || k3s2)) return false;
     if (k7x1 && d->pad_w != 0) return false;
     if (k4x1 && d->pad_w != 0) return false;
     if (d->pad_mode != 0 && d->pad_mode != 1) return false;
     if (d->pad_mode == 1 && (d->pad_h >= d->Hin || d->pad_w >= d->Win)) return false;
-    const long Q = (long)d->N * d->Hout * d->Wout, Pv = (long)d->N * d->Hin * d->Win;
-    if (Q * d->Cout * 2 >= (1L << 31) || Pv * d->Cin * 2 >= (1L << 31)) return false;
     *g = WgradLineGeom{};
-    g->N = d->N; g->Hq = d->Hout; g->Wq = d->Wout; g->Hv = d->Hin; g->Wv = d->Win; g->Ca = d->Cout; g->Cb = d->Cin;
+    g->N = d->N;
+    if (!d->transposed) {   // U = gradient of the output (a = cout), V = input (b = cin)
+        g->Hq = d->Hout; g->Wq = d->Wout; g->Hv = d->Hin; g->Wv = d->Win; g->Ca = d->Cout; g->Cb = d->Cin;
+    } else {                // ConvTranspose2d: U = input (a = cin), V = gradient of the output (b = cout)
+        g->Hq = d->Hin; g->Wq = d->Win; g->Hv = d->Hout; g->Wv = d->Wout; g->Ca = d->Cin; g->Cb = d->Cout;
+    }
+    const long Q = (long)d->N * g->Hq * g->Wq, Pv = (long)d->N * g->Hv * g->Wv;
+    if (Q * g->Ca * 2 >= (1L << 31) || Pv * g->Cb * 2 >= (1L << 31)) return false;
     g->stride_y = d->stride_h; g->pad_mode = d->pad_mode; g->dy0 = -d->pad_h; g->dx0 = -d->pad_w;
-    g->segs = (d->Wout + 63) / 64;
-    const long ksteps = (long)d->N * d->Hout * g->segs;
+    g->segs = (g->Wq + 63) / 64;
+    const long ksteps = (long)d->N * g->Hq * g->segs;
     if (ksteps >= (1L << 30)) return false;
     g->ksteps = (int)ksteps;
     // one workgroup per CU: ~256 workgroups, at least 8 K-steps each, no empty split
-    const long tiles = (long)(d->Cout / 64) * (d->Cin / 64);
+    const long tiles = (long)(g->Ca / 64) * (g->Cb / 64);
     long ks = (256 + tiles - 1) / tiles;
     if (ks > ksteps / 8) ks = ksteps / 8;
     if (ks < 1) ks = 1;
     if (ks > 256) ks = 256;
     g->per = (int)((ksteps + ks - 1) / ks);
     g->ksplit = (int)((ksteps + g->per - 1) / g->per);
-    g->u_bytes = (unsigned)(Q * d->Cout * 2); g->v_bytes = (unsigned)(Pv * d->Cin * 2);
+    g->u_bytes = (unsigned)(Q * g->Ca * 2); g->v_bytes = (unsigned)(Pv * g->Cb * 2);
     return true;
 }
 
@@ -1002,7 +1025,8 @@ static void launch_line(const ir2rgb_conv_desc *d, const WgradLineGeom &g, const
     const unsigned grid = (unsigned)((long)g.ksplit * (g.Ca / 64) * (g.Cb / 64));
     static int ring = -1;           // IR2RGB_WGRAD_RING=0: the k x 1 layers on the row-major line kernel (A/B measurements)
     if (ring < 0) { const char *e = getenv("IR2RGB_WGRAD_RING"); ring = e ? atoi(e) : 1; }
-    if (d->kh == 7 && ring && d->stride_h == 1) conv_wgrad_col_kernel<DT, 7, 1><<<grid, 512, 0, s>>>(U, V, D, g);
+    if (d->kh == 3 && d->kw == 3) conv_wgrad_line_kernel<DT, 3, 3, 2><<<grid, 512, 0, s>>>(U, V, D, g);
+    else if (d->kh == 7 && ring && d->stride_h == 1) conv_wgrad_col_kernel<DT, 7, 1><<<grid, 512, 0, s>>>(U, V, D, g);
     else if (d->kh == 4 && ring && d->stride_h == 2) conv_wgrad_col_kernel<DT, 4, 2><<<grid, 512, 0, s>>>(U, V, D, g);
     else if (d->kh == 7) conv_wgrad_line_kernel<DT, 7, 1><<<grid, 512, 0, s>>>(U, V, D, g);
     else if (d->kw == 7) conv_wgrad_line_kernel<DT, 1, 7><<<grid, 512, 0, s>>>(U, V, D, g);

@@ -276,6 +276,10 @@ def test_xexpand_bwd_row_tile_kernel_vs_autograd(dev, case):
     (64, 8, 128, 64, 3, 1, 1, 0, False, 0),       # nine-tap kernel, zero padding, two segments per row, split-K
     (128, 5, 64, 192, 3, 1, 1, 0, False, 0),      # nine-tap kernel, 3 x 2 tiles, odd row count
     (128, 6, 192, 64, 3, 1, 1, 1, False, 0),      # nine-tap kernel, reflect, three segments per row
+    (64, 33, 47, 128, 3, 2, 1, 0, False, 0),      # stride-2 3x3 (parity-split patch), odd sizes, one ragged segment
+    (64, 20, 300, 64, 3, 2, 1, 0, False, 0),      # ... three segments per output row, the last one ragged
+    (128, 9, 70, 64, 3, 2, 1, 0, True, 1),        # ... transposed, two segments per input row
+    (256, 16, 32, 128, 3, 2, 1, 0, False, 0),     # ... 2 x 4 channel tiles
 ])
 def test_wgrad_kernel_vs_torch(dev, dtype, case):
     """MFMA weight-gradient kernel alone (transposed LDS reads, split-K atomics) vs torch's fp32
