@@ -460,8 +460,14 @@ class Vid2VidTrainer:
             m.to(device).train()
             m.compute_dtype = o["compute_dtype"]
         import os
+        # gloo (the CPU-side rehearsal backend) moves CUDA tensors through the host and synchronises the device: next to it a
+        # second stream under autograd is pathological (the two-rank rehearsal of bench.py: 7.9 s per window with the
+        # finer-scale generators' branches on two streams, 0.39 s without; the discriminators' streams cost 30 ms there).
+        # RCCL ranks keep all streams (tests/test_rccl_gpu.py).
+        gloo = world_size > 1 and dist.is_available() and dist.is_initialized() and dist.get_backend() != "nccl"
+        fine = os.environ.get("IR2RGB_BRANCH_FINE", "0" if gloo else "1") != "0"
         for g in self.netG[1:]:
-            g.branch_streams_training = bool(o["branch_streams_fine_scales"]) and os.environ.get("IR2RGB_BRANCH_FINE", "1") != "0"
+            g.branch_streams_training = bool(o["branch_streams_fine_scales"]) and fine
         self.d_streams = bool(o["discriminator_streams"]) and os.environ.get("IR2RGB_D_STREAMS", "1") != "0" and device.type == "cuda"
         self.adam_stream_on = os.environ.get("IR2RGB_ADAM_STREAM", "1" if o["adam_stream"] else "0") != "0" and device.type == "cuda"
         self._adam_stream, self._adam_pending = None, False
