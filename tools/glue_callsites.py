@@ -5,9 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ir2rgb_amd import vid2vid as V
 dev = torch.device("cuda:0")
-tr = V.Vid2VidTrainer(dev, n_scales_spatial=2)
-A, B = V.synthetic_sequence(16, 512, 1024, 1234, dev)
-for i in range(4):
+tr = V.Vid2VidTrainer(dev, n_scales_spatial=2, resident_inputs=True)
+A, B = V.synthetic_sequence(24, 512, 1024, 1234, dev)
+for i in range(14):
     tr.train_window(A[:, i:i + 3], B[:, i:i + 3])
 torch.cuda.synchronize()
 agg = collections.defaultdict(lambda: [0, 0])
@@ -47,7 +47,7 @@ for name in ("zero_", "new_zeros", "clone"):
             return r
         return w
     setattr(torch.Tensor, name, mk(name, getattr(torch.Tensor, name)))
-tr.train_window(A[:, 5:8], B[:, 5:8])
+tr.train_window(A[:, 15:18], B[:, 15:18])
 torch.cuda.synchronize()
 for (k, s), (n, b) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:50]:
     print("%-11s %4d %9.2f MB  %s" % (k, n, b / 1e6, s))
