@@ -37,7 +37,40 @@ adam_kernel(const AdamTensor *__restrict__ table, const int2 *__restrict__ block
     const long e0 = (long)tb.y * ADAM_CHUNK;
     const long e1 = min(t.n, e0 + ADAM_CHUNK);
     const bool vec = ((((uintptr_t)t.p | (uintptr_t)t.g | (uintptr_t)t.m | (uintptr_t)t.v) & 15) == 0);
-    if (vec) {
+    if (vec && e1 - e0 == ADAM_CHUNK) {
+        // a whole chunk (all but the last one of a tensor): no per-load bounds, global (not flat) accesses, and the
+        // streams that nobody reads again before the next step (the gradient in, the two moments out) bypass the caches
+        typedef float vf4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(1))) vf4 gf4;
+        gf4 *p4 = (gf4 *)(uintptr_t)t.p, *m4 = (gf4 *)(uintptr_t)t.m, *v4 = (gf4 *)(uintptr_t)t.v;
+        const gf4 *g4 = (const gf4 *)(uintptr_t)t.g;
+        const long q0 = (e0 >> 2) + threadIdx.x;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            vf4 P[4], G[4], M[4], V[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long q = q0 + (half * 4 + u) * 256;
+                P[u] = p4[q];
+                G[u] = __builtin_nontemporal_load(&g4[q]);
+                M[u] = m4[q];
+                V[u] = v4[q];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long q = q0 + (half * 4 + u) * 256;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float pp = P[u][c], mm = M[u][c], vv = V[u][c];
+                    adam_one(pp, G[u][c], mm, vv, k);
+                    P[u][c] = pp; M[u][c] = mm; V[u][c] = vv;
+                }
+                p4[q] = P[u];
+                __builtin_nontemporal_store(M[u], &m4[q]);
+                __builtin_nontemporal_store(V[u], &v4[q]);
+            }
+        }
+    } else if (vec) {
         const long q1 = e1 >> 2;   // whole float4s below e1 (e0 is a multiple of 4)
         float4 *p4 = (float4 *)t.p, *m4 = (float4 *)t.m, *v4 = (float4 *)t.v;
         const float4 *g4 = (const float4 *)t.g;
