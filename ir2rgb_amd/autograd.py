@@ -516,8 +516,9 @@ class ConvStageFn(Function):
         plan = ctx.plan
         if plan is not None:
             conv = ctx.conv
-            if not getattr(conv, "_ir2rgb_bwd", 0) and getattr(conv, "_ir2rgb_active", None) is None and not SC.ENABLED:
-                return plan.backward(ctx, gz)
+            if not SC.ENABLED and (plan.groups > 1 or (not getattr(conv, "_ir2rgb_bwd", 0) and
+                                                        getattr(conv, "_ir2rgb_active", None) is None)):
+                return plan.backward(ctx, gz)       # (a grouped plan handles the backward flags itself)
             # backward flags on a planned stage (a discriminator run without sample groups): the general code below
             xin, y, vec = ctx.saved_tensors
             scale, shift, mean, invstd = vec.unbind(0)

@@ -236,6 +236,62 @@ def test_planned_stage_equals_the_general_stage(dev, dtype, case):
         assert torch.isfinite(a.float()).all()
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [
+    # Cin, H, W, Cout, k, stride, pad, groups, group order, active groups in the flagged pass
+    (64, 33, 65, 128, 4, 2, 2, 3, (2, 0, 1), 2),      # image discriminator layer: three groups, the generator's pass on two
+    (128, 17, 33, 256, 4, 1, 2, 2, (1, 0), 1),        # temporal discriminator layer, stride 1: two groups, one active
+    (64, 70, 200, 128, 4, 2, 2, 3, None, 2),          # > 128 statistics rows per group: finalize + apply launches
+])
+def test_planned_grouped_stage_equals_the_general_stage(dev, dtype, case):
+    """stageplan.GroupedStagePlan (batched discriminator stages: BatchNorm per sample group, backward flags, passes with
+    inactive groups) against ConvStageFn's general code: forward, a flagged pass (no parameter gradients, leading groups
+    only) and a full pass (parameter gradients, accumulated in the kernel on top of an earlier one), bit for bit."""
+    import copy
+    from ir2rgb_amd import autograd as A, conv as C, layers as L, stageplan
+    cin, h, w, cout, k, s, p, G, order, active = case
+    gen = torch.Generator().manual_seed(cin + h + G)
+    x0 = torch.randn(2 * G, cin, h, w, generator=gen).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    conv0 = torch.nn.Conv2d(cin, cout, k, s, p).to(dev)
+    bn0 = torch.nn.BatchNorm2d(cout).to(dev)
+    with torch.no_grad():
+        bn0.weight.normal_(1.0, 0.2)
+        bn0.bias.normal_(0.0, 0.2)
+    results = []
+    for lean in (True, False):
+        stageplan.ENABLED = lean
+        try:
+            conv, bn = copy.deepcopy(conv0), copy.deepcopy(bn0)
+            holder = torch.nn.Sequential(conv, bn)
+            outs = []
+            for rep in range(2):
+                x = x0.clone().requires_grad_(True)
+                with L.repeated_forward(tuple(range(1, G + 1))):
+                    z = A.conv_stage(x, conv, bn, L.ACT_LEAKY, C.PAD_ZERO, dtype, groups=G, group_order=order, training=True)
+                L.flush_bn_counters()
+                g = torch.randn(z.shape, generator=torch.Generator().manual_seed(7 + rep)).to(dev).to(dtype).contiguous(
+                    memory_format=torch.channels_last)
+                na = z.shape[0] // G * active
+                with A.backward_flags([holder], A.SKIP_PARAM_GRADS, active):
+                    z.backward(g, retain_graph=True, inputs=[x])
+                dx_part = x.grad[:na].clone()
+                assert conv.weight.grad is None or rep > 0
+                x.grad = None
+                with A.backward_flags([holder], A.SKIP_INPUT_GRAD):
+                    z.backward(g, inputs=[x, conv.weight, bn.weight, bn.bias])
+                outs += [z.detach().clone(), dx_part, x.grad.clone()]
+            outs += [conv.weight.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(), bn.running_mean.clone(),
+                     bn.running_var.clone(), bn.num_batches_tracked.clone()]
+            planned = any(isinstance(v, stageplan.GroupedStagePlan) for v in conv.__dict__.get("_ir2rgb_plans", {}).values())
+            assert planned == lean
+            results.append(outs)
+        finally:
+            stageplan.ENABLED = True
+    for i, (a, b) in enumerate(zip(*results)):
+        assert torch.equal(a, b), f"output {i} differs between the planned and the general grouped stage"
+        assert torch.isfinite(a.float()).all()
+
+
 @pytest.mark.parametrize("case", [
     # Cin, W, KW, stride, pad, reflect
     (9, 300, 7, 1, 3, 1),       # the generators' 7-wide first layer: three 128-column tiles, ragged last one, both mirrors
