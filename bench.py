@@ -157,6 +157,21 @@ def config3_operators(dev):
     img, flow = torch.randn(1, 3, H, W, device=dev), torch.randn(1, 2, H, W, device=dev) * 4
     corr, res, cn = Correlation(20, 1, 20, 1, 2, 1), Resample2d(), ChannelNorm()
     out = {}
+
+    def graphed_us(fn, reps=20):
+        """Device time per launch: ``reps`` calls captured in one HIP graph (no Python / launch overhead between them)."""
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            fn()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                keep = [fn() for _ in range(reps)]
+        torch.cuda.current_stream(dev).wait_stream(side)
+        ms = _timed(graph.replay, 10, warm=2)
+        del keep
+        return ms * 1e3 / reps
+
     with torch.no_grad():
         for name, fn, mb, gflop in (("correlation_fwd_fp32_nchw", lambda: corr(f1, f2), 31.2, 1.85),
                                     ("resample2d_fwd", lambda: res(img, flow), 16.8, None),
@@ -165,6 +180,12 @@ def config3_operators(dev):
             out[name] = {"us": round(us, 1), "GB_per_s": round(mb * 1e6 / (us * 1e-6) / 1e9, 0), "frac_of_hbm_peak": round(mb * 1e6 / (us * 1e-6) / 8e12, 3)}
             if gflop:
                 out[name]["TFLOPs"] = round(gflop * 1e3 / us, 1)
+            try:        # the same launches replayed from a HIP graph: the kernels' own time
+                gus = graphed_us(fn)
+                out[name].update({"hip_graph_us": round(gus, 1), "hip_graph_GB_per_s": round(mb * 1e6 / (gus * 1e-6) / 1e9, 0),
+                                  "hip_graph_frac_of_hbm_peak": round(mb * 1e6 / (gus * 1e-6) / 8e12, 3)})
+            except RuntimeError as e:   # (a capture that fails leaves the API-level number standing)
+                out[name]["hip_graph_error"] = str(e)[:120]
         # the form FlowNet2 runs inside this package: half NHWC feature maps -> banded MFMA products, fp32 planes out
         a = f1.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         b = f2.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
@@ -179,7 +200,8 @@ def config3_operators(dev):
         mb = (2 * 4.19 + 14.45)
         out["correlation_fwd_nhwc_half_mfma"] = {"us": round(us, 1), "GB_per_s": round(mb * 1e6 / (us * 1e-6) / 1e9, 0),
                                                  "TFLOPs_useful": round(1.85e3 / us, 1)}
-    out["note"] = "API-level launches incl. the Python operator wrappers (allocation of the output); kernel-only times: profiles/"
+    out["note"] = ("us: API-level launches incl. the Python operator wrappers (allocation of the output, autograd Function); "
+                   "hip_graph_us: the same launches replayed from a HIP graph, 20 per replay (device time per launch)")
     return out
 
 
